@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py — frames/sec end-to-end (net + key-point grouping) at 368 px on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" is one pass of the hot path (network forward + peak extraction + PAF
+grouping + result fetch to the host) over one batch of synthetic frames that are already resident in
+HBM (normalised float32 NCHW).  Default workload = BASELINE.json configs[1]: batch 1, 368x656, one
+refinement stage, fp32.  Frames shard across ranks with no data-path collective (weights are broadcast
+once over RCCL at start-up), so scaling is weak: every rank processes `--batch` frames per step.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline / cpu_baseline fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}
+
+
+def layer_work(layers, N, H, W, elt_bytes=4):
+    """Algorithmic FLOPs (2*MAC) and bytes (in + out + weights at the storage dtype) per layer class."""
+    h, w = H, W
+    acc = {"stem": [0.0, 0.0], "depthwise": [0.0, 0.0], "pointwise_1x1": [0.0, 0.0], "dense_3x3": [0.0, 0.0]}
+    for l in layers:
+        hi, wi = h, w
+        if l["stride"] == 2:
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        m_out = N * h * w
+        if l["kind"] == 0:
+            k = "stem"
+            flops = 2.0 * m_out * 27 * 32
+            byt = (N * hi * wi * 3 + m_out * 32) * 4 + 27 * 32 * 4
+        elif l["kind"] == 1:
+            k = "depthwise"
+            flops = 2.0 * m_out * 9 * l["cin"]
+            byt = (N * hi * wi * l["cin"] + m_out * l["cout"] + 9 * l["cin"]) * elt_bytes
+        else:
+            k = "pointwise_1x1" if l["ksize"] == 1 else "dense_3x3"
+            flops = 2.0 * m_out * l["cin"] * l["cout"] * l["ksize"] ** 2
+            byt = (m_out * (l["cin"] + l["cout"]) + l["cin"] * l["cout"] * l["ksize"] ** 2) * elt_bytes
+        acc[k][0] += flops
+        acc[k][1] += byt
+    return acc
+
+
+def cpu_baseline(sd, x, nref, budget_s=20.0):
+    """The oracle (CPU restatement, stock torch.nn CPU kernels + NumPy post-processing) timed on this box's
+    host cores on the same workload: demo.py --cpu semantics, one frame per iteration."""
+    import torch
+    from oracle import net_ref, post_ref
+
+    def one(frame):
+        outs = net_ref.forward(sd, frame, nref)
+        hu = post_ref.upsample_cubic(outs[-2][0].numpy().transpose(1, 2, 0), 4)
+        pu = post_ref.upsample_cubic(outs[-1][0].numpy().transpose(1, 2, 0), 4)
+        by_type, total = [], 0
+        for k in range(18):
+            total += post_ref.extract_keypoints(hu[:, :, k], by_type, total)
+        post_ref.group_keypoints(by_type, pu, demo=True)
+
+    xt = torch.from_numpy(x)
+    one(xt[0:1])
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one(xt[n % xt.shape[0]:n % xt.shape[0] + 1])
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d frames of the same 368x656 synthetic workload, %.1f s, oracle net (torch CPU) + NumPy post" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=368)
+    ap.add_argument("--width", type=int, default=656)
+    ap.add_argument("--nref", type=int, default=1)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    import torch
+    import lwpose_amd  # noqa: F401
+    from lwpose_amd import dist as lwdist, synth, workload
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # weights: rank 0 builds + calibrates, then ONE RCCL broadcast of the packed blob (no per-step comms)
+    net, sd = lwdist.build_replicated_net(args.nref, 1, local_rank, args.dtype, args.height, args.width, rank, world)
+    eng = net.engine
+
+    # this rank's shard of the global batch: frames [rank*B, (rank+1)*B)
+    frames = synth.make_frames(args.batch, args.height, args.width, seed0=rank * args.batch)
+    x_np = workload.normalized_input(frames)
+    x = torch.from_numpy(x_np).cuda(local_rank)
+
+    def step():
+        eng.infer_poses_async(x, 4, True)
+        return eng.fetch_poses()
+
+    for _ in range(args.warmup):
+        res = step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_frames = world * args.batch * args.steps
+        # device-only rates (HIP events on the engine's stream) and per-class launch times
+        dev_ms = eng.time_pipeline(x, 20, what=1) / 20.0
+        net_ms = eng.time_pipeline(x, 20, what=0) / 20.0
+        classes = eng.profile_classes(x, reps=10)
+        work = layer_work(eng.layers(), args.batch, args.height, args.width, 4 if args.dtype == "fp32" else 2)
+        roofs = {}
+        for k, (flops, byt) in work.items():
+            ms, nl = classes[k]["ms"], max(classes[k]["launches"], 1)
+            if ms <= 0:
+                continue
+            if k in ("depthwise", "stem"):
+                ach = byt / (ms * 1e-3) / 1e9
+                roofs[k] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                            "traffic": None, "avg_launch_us": ms * 1e3 / nl, "launches": nl, "alg_bytes_per_launch": byt / nl}
+            else:
+                ach = flops / (ms * 1e-3) / 1e12
+                pk = MFMA_PEAK_TFLOPS[args.dtype]
+                roofs[k] = {"bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk,
+                            "traffic": None, "avg_launch_us": ms * 1e3 / nl, "launches": nl, "alg_flops_per_launch": flops / nl}
+        dominant = max(roofs, key=lambda k: classes[k]["ms"])
+        roof = dict(roofs[dominant], kernel=dominant)
+        out = {
+            "metric": "frames/sec end-to-end (net+grouping) at 368px",
+            "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "batch=%d per GPU, %dx%d frames, %d refinement stage(s), %s convs / f32+f64 post, "
+                                   "resident normalised NCHW input -> key-points + pose entries on host"
+                                   % (args.batch, args.height, args.width, args.nref, args.dtype),
+                       "global_batch": world * args.batch, "parallelism": "dp%d (frames sharded, no data-path collective)" % world},
+            "roofline": roof,
+            "roofline_classes": roofs,
+            "device_ms_per_step": {"pipeline": dev_ms, "network_only": net_ms, "post_only": max(dev_ms - net_ms, 0.0),
+                                   "class_ms": {k: v["ms"] for k, v in classes.items()}},
+            "poses_per_frame": float(np.mean([len(r[0]) for r in res])),
+            "keypoints_per_frame": float(np.mean([len(r[1]) for r in res])),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, x_np, args.nref, args.cpu_budget)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/*
+ * lwpose.h — C ABI of the MI355X-native Lightweight-OpenPose inference path.
+ *
+ * The reference (vivek87799/lightweight-human-pose-estimation.pytorch) is pure Python and has no
+ * FFI/plugin registry; its drop-in boundary is duck typing at a few Python call sites.  This header
+ * is what a binding for those call sites talks to (the ctypes stub is in INTEGRATION.md and in
+ * lwpose_amd/_lib.py).  Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns int: 0 = LWP_OK, negative = error class; nothing throws across the ABI;
+ *     lwp_last_error(h) returns a human-readable message for the last failing call on that handle
+ *     (h == NULL: last failure of a call that had no handle).
+ *   - plain pointers and sizes only; the caller owns every buffer it passes, the handle owns all
+ *     device memory it allocates.  Pointer arguments tagged "mem" accept host or device memory
+ *     according to the LWP_MEM_* flag passed with them (device pointers = zero-copy from
+ *     torch-ROCm tensors via data_ptr()).
+ *   - one handle per (device, stream); a handle is not thread-safe; distinct handles are independent.
+ *   - all maps are float32.  Network tensors crossing the ABI are NCHW (as the reference's
+ *     nn.Module sees them); post-processing maps are HWC (as numpy sees them after demo.py:71-76).
+ */
+#ifndef LWPOSE_H
+#define LWPOSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lwp_context* lwp_handle;
+
+enum {
+    LWP_OK = 0,
+    LWP_ERR_ARG = -1,       /* bad argument / shape                               */
+    LWP_ERR_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+    LWP_ERR_STATE = -3,     /* call order (e.g. forward before load_weights)       */
+    LWP_ERR_CAPACITY = -4,  /* a peak / key-point / connection list overflowed its configured capacity */
+    LWP_ERR_NOGPU = -5,     /* no usable HIP device                                */
+    LWP_ERR_UNBOUND = -6    /* the reference would raise UnboundLocalError here (keypoints.py:116,137) */
+};
+
+enum { LWP_MEM_HOST = 0, LWP_MEM_DEVICE = 1 };
+enum { LWP_F32 = 0, LWP_BF16 = 1 };   /* storage/MFMA dtype of the conv stack; accumulation, bias,
+                                         activations and all post-processing are always f32/f64 */
+
+/* role codes returned by lwp_param_spec */
+enum { LWP_ROLE_CONV_W = 0, LWP_ROLE_CONV_B = 1, LWP_ROLE_BN_W = 2, LWP_ROLE_BN_B = 3,
+       LWP_ROLE_BN_MEAN = 4, LWP_ROLE_BN_VAR = 5, LWP_ROLE_BN_NBT = 6 };
+
+int lwp_version(void);
+
+/* ---- parameter table: replaces nn.Module.state_dict() key/shape enumeration
+ *      (models/with_mobilenet.py:89-112 + modules/conv.py:4-32; consumed by modules/load_state.py:4-15).
+ *      No GPU needed. */
+int lwp_param_count(int num_refinement_stages, int num_channels, int num_heatmaps, int num_pafs);
+int lwp_param_spec(int num_refinement_stages, int num_channels, int num_heatmaps, int num_pafs,
+                   int index, char* name, int name_cap, int64_t shape[4], int* ndim, int* role);
+
+/* ---- lifetime: replaces PoseEstimationWithMobileNet(...) + net.cuda() (demo.py:156, demo.py:82-84) */
+int lwp_create(int device_id, int num_refinement_stages, int num_channels, int num_heatmaps,
+               int num_pafs, int dtype, lwp_handle* out);
+int lwp_destroy(lwp_handle h);
+const char* lwp_last_error(lwp_handle h);
+
+/* capacities of the post-processing lists (defaults 2048 / 128 / 4096 / 256); overflow => LWP_ERR_CAPACITY */
+int lwp_set_capacity(lwp_handle h, int max_peaks_per_channel, int max_kpts_per_type,
+                     int max_connections_per_limb, int max_pose_entries);
+
+/* ---- weights: replaces net.load_state_dict(...) at the end of load_state (modules/load_state.py:15).
+ *      names[i] = state_dict key, ptrs[i] = host float32 data (int64 for num_batches_tracked, ignored),
+ *      shapes = n x 4 (unused dims 1), ndims[i].  Conv weights OIHW.  Every key of lwp_param_spec must
+ *      be present with the right shape.  Folds eval-mode BatchNorm (eps 1e-5, modules/conv.py:7) into
+ *      the preceding conv, repacks to the kernels' layouts and uploads one blob. */
+int lwp_load_weights(lwp_handle h, const char* const* names, const void* const* ptrs,
+                     const int64_t* shapes, const int* ndims, int n);
+
+/* packed weight blob, for one-shot replication to other GPUs (RCCL broadcast done by the host side
+ * on a device buffer; replaces nn.DataParallel's per-iteration replicate, train.py:74). */
+int lwp_weights_blob_bytes(lwp_handle h, size_t* bytes);
+int lwp_weights_blob_export(lwp_handle h, void* dst_device, size_t bytes);
+int lwp_weights_blob_import(lwp_handle h, const void* src_device, size_t bytes);
+
+/* ---- network forward: replaces net(tensor_img) (demo.py:68, val.py:94;
+ *      PoseEstimationWithMobileNet.forward, models/with_mobilenet.py:114-123).
+ *      in: N x 3 x H x W float32 (mem).  outs: 2*(1+nref) pointers (mem, same kind as out_mem) to
+ *      N x {num_heatmaps | num_pafs} x H/8 x W/8 float32 in the order [heat0, paf0, heat1, paf1, ...].
+ *      H and W must be multiples of 8 (the reference pads to the stride, val.py:36-49).
+ *      Runs on the handle's stream and synchronises it before returning when out_mem is host. */
+int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int H, int W,
+                float* const* outs, int out_mem);
+
+/* ---- bicubic up-sampling: replaces cv2.resize(map, (0,0), fx=r, fy=r, INTER_CUBIC) on float maps
+ *      (demo.py:72,76; val.py:98,105).  src: N x C x h x w (mem);  dst: N x (h*r) x (w*r) x C (mem). */
+int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, int C, int hs, int ws, int ratio,
+                 float* dst, int dst_mem);
+
+/* ---- extract_keypoints: replaces modules/keypoints.py:16-48 for one heat-map channel.
+ *      heatmap: H x W float32 with row stride `row_stride` and pixel stride `pix_stride` (elements), host.
+ *      It is thresholded IN PLACE (values < 0.1 -> 0) like the reference.  Outputs (host, capacity `cap`):
+ *      xs, ys (int64), scores (float32) in the reference's order (x ascending, then y).  *count = number
+ *      kept after the radius-6 suppression; ids are total_keypoint_num + index (caller side). */
+int lwp_extract_keypoints(lwp_handle h, float* heatmap, int H, int W, int64_t row_stride, int64_t pix_stride,
+                          int64_t* xs, int64_t* ys, float* scores, int cap, int* count);
+
+/* ---- group_keypoints: replaces modules/keypoints.py:51-201.
+ *      kpts: K x 4 float64 rows (x, y, score, id) concatenated by type; type_counts[18].
+ *      pafs: H x W x num_pafs float32 HWC (mem).  demo != 0 -> int() truncation, else round-half-even.
+ *      pose_entries: cap_entries x 20 float64 out; *n_entries out. */
+int lwp_group_keypoints(lwp_handle h, const double* kpts, const int* type_counts,
+                        const float* pafs, int pafs_mem, int H, int W, int demo,
+                        double* pose_entries, int cap_entries, int* n_entries);
+
+/* ---- fused frame pipeline: replaces the body of run_demo's loop up to group_keypoints
+ *      (demo.py:93-100: infer_fast -> 18 x extract_keypoints -> group_keypoints) for a batch.
+ *      in: N x 3 x H x W float32, already normalised and padded (mem).  The up-sampled maps are never
+ *      materialised: peaks and PAF samples are interpolated on the fly with the same arithmetic.
+ *      Outputs (host): for frame f, kpt_counts[f*18 + t] key-points of type t; kpts rows
+ *      (x, y, score, id) float64 at kpts + f*kpt_cap*4; entries at entries + f*entry_cap*20;
+ *      n_entries[f]. */
+int lwp_infer_poses(lwp_handle h, const float* in, int in_mem, int N, int H, int W,
+                    int upsample_ratio, int demo,
+                    int* kpt_counts, double* kpts, int kpt_cap,
+                    double* entries, int entry_cap, int* n_entries);
+
+/* same post-processing from already computed low-resolution stage outputs (the tensors net(x) returns,
+ * demo.py:70,74): heat N x num_heatmaps x h x w, paf N x num_pafs x h x w, NCHW float32 (mem). */
+int lwp_poses_from_maps(lwp_handle h, const float* heat, const float* paf, int mem, int N, int hs, int ws,
+                        int upsample_ratio, int demo,
+                        int* kpt_counts, double* kpts, int kpt_cap,
+                        double* entries, int entry_cap, int* n_entries);
+
+/* enqueue-only variant for benchmarking / pipelining: same work, results stay on the device until
+ * lwp_fetch_poses; does not synchronise.  `in` must be device memory. */
+int lwp_infer_poses_async(lwp_handle h, const float* in_device, int N, int H, int W,
+                          int upsample_ratio, int demo);
+int lwp_fetch_poses(lwp_handle h, int* kpt_counts, double* kpts, int kpt_cap,
+                    double* entries, int entry_cap, int* n_entries);
+
+/* ---- measurement helpers (bench.py): time `iters` back-to-back enqueues with HIP events on the
+ *      handle's own stream.  what: 0 = forward only, 1 = full infer_poses.  ms_total out. */
+int lwp_time_pipeline(lwp_handle h, const float* in_device, int N, int H, int W, int upsample_ratio,
+                      int demo, int what, int iters, float* ms_total);
+/* per-kernel-class device time of ONE pass, measured with HIP events around each launch on the
+ * handle's stream: classes 0=stem 1=depthwise 2=pointwise-1x1 3=dense-3x3 4=post 5=other.
+ * ms[6], launches[6] out. */
+int lwp_profile_classes(lwp_handle h, const float* in_device, int N, int H, int W, int upsample_ratio,
+                        int demo, int reps, float* ms, int* launches);
+int lwp_synchronize(lwp_handle h);
+
+/* ---- introspection / per-layer parity (tests): the layer list mirrors the module tree of
+ *      models/with_mobilenet.py:92-112.  lwp_debug_layer_output runs the first layer_index+1 layers on
+ *      `in` (host, N x 3 x H x W) and copies that layer's output to dst (host) as NCHW float32
+ *      N x cout x h x w; dims are returned in out_dims[4]. */
+int lwp_layer_count(lwp_handle h);
+int lwp_layer_info(lwp_handle h, int layer_index, char* name, int name_cap, int* kind, int* cin, int* cout,
+                   int* ksize, int* stride, int* dilation);
+int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int H, int W, int layer_index,
+                           float* dst, size_t dst_floats, int out_dims[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LWPOSE_H */

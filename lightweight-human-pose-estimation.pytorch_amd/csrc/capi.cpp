@@ -1,0 +1,725 @@
+// C-ABI entry points (include/lwpose.h).  Host orchestration only: buffer management, the static
+// launch sequence of the layer graph on the handle's HIP stream, result fetch, and event timing.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "lwp_internal.h"
+
+using namespace lwp;
+
+struct lwp_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int dtype = LWP_F32;
+    Graph g;
+    float* d_blob = nullptr;
+    bool weights_loaded = false;
+    // activations for the current (N, H, W)
+    int cur_N = 0, cur_H = 0, cur_W = 0;
+    std::vector<float*> bufs;
+    float* d_in = nullptr; size_t d_in_bytes = 0;
+    std::vector<float*> d_outs;            // NCHW staging for host outputs
+    std::vector<size_t> d_outs_bytes;
+    float* d_tmp = nullptr; size_t d_tmp_bytes = 0;     // generic device staging (upsample / extract / group)
+    float* d_tmp2 = nullptr; size_t d_tmp2_bytes = 0;
+    // post-processing
+    PostCaps caps;
+    PostWorkspace ws;
+    // pinned host staging for results
+    void* h_stage = nullptr; size_t h_stage_bytes = 0;
+    int last_N = 0;
+    // per-launch profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_class;
+    size_t ev_used = 0;
+    std::string err;
+};
+
+static std::string g_err;
+static std::mutex g_mu;
+
+static int fail(lwp_context* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    else { std::lock_guard<std::mutex> l(g_mu); g_err = msg; }
+    return code;
+}
+#define HIP_TRY(h, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, LWP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+static int ensure_dev(lwp_context* h, float** p, size_t* have, size_t need) {
+    if (*have >= need) return LWP_OK;
+    if (*p) HIP_TRY(h, hipFree(*p));
+    *p = nullptr; *have = 0;
+    HIP_TRY(h, hipMalloc((void**)p, need));
+    *have = need;
+    return LWP_OK;
+}
+
+extern "C" int lwp_version(void) { return 100; }
+
+extern "C" int lwp_param_count(int nref, int C, int NH, int NP) {
+    if (nref < 0 || C <= 0 || NH <= 0 || NP <= 0) return LWP_ERR_ARG;
+    return (int)param_table(nref, C, NH, NP).size();
+}
+
+extern "C" int lwp_param_spec(int nref, int C, int NH, int NP, int index, char* name, int name_cap, int64_t shape[4],
+                              int* ndim, int* role) {
+    if (nref < 0 || C <= 0 || NH <= 0 || NP <= 0 || !name || !shape || !ndim || !role) return fail(nullptr, LWP_ERR_ARG, "bad argument");
+    auto t = param_table(nref, C, NH, NP);
+    if (index < 0 || index >= (int)t.size()) return fail(nullptr, LWP_ERR_ARG, "index out of range");
+    if ((int)t[index].key.size() + 1 > name_cap) return fail(nullptr, LWP_ERR_ARG, "name buffer too small");
+    std::strcpy(name, t[index].key.c_str());
+    for (int d = 0; d < 4; ++d) shape[d] = t[index].shape[d];
+    *ndim = t[index].ndim;
+    *role = t[index].role;
+    return LWP_OK;
+}
+
+extern "C" const char* lwp_last_error(lwp_handle h) {
+    if (h) return h->err.c_str();
+    std::lock_guard<std::mutex> l(g_mu);
+    return g_err.c_str();
+}
+
+extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dtype, lwp_handle* out) {
+    if (!out) return fail(nullptr, LWP_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (nref < 0 || C <= 0 || C % 32 || NH <= 0 || NP <= 0) return fail(nullptr, LWP_ERR_ARG, "bad network shape (num_channels must be a multiple of 32)");
+    if (dtype != LWP_F32 && dtype != LWP_BF16) return fail(nullptr, LWP_ERR_ARG, "bad dtype");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, LWP_ERR_NOGPU, "no HIP device available");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, LWP_ERR_ARG, "device_id out of range");
+    hipError_t e = hipSetDevice(device_id);
+    if (e != hipSuccess) return fail(nullptr, LWP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return fail(nullptr, LWP_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(nullptr, LWP_ERR_NOGPU, std::string("this library is built for gfx950 only, found ") + prop.gcnArchName);
+    lwp_context* h = new lwp_context();
+    h->device = device_id;
+    h->dtype = dtype;
+    h->g = build_graph(nref, C, NH, NP);
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    e = init_cubic_tables();
+    if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("init_cubic_tables: ") + hipGetErrorString(e)); }
+    e = hipMalloc((void**)&h->d_blob, h->g.blob_floats * sizeof(float));
+    if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("hipMalloc(blob): ") + hipGetErrorString(e)); }
+    h->bufs.assign(h->g.bufs.size(), nullptr);
+    h->d_outs.assign(2 * (1 + nref), nullptr);
+    h->d_outs_bytes.assign(2 * (1 + nref), 0);
+    *out = h;
+    return LWP_OK;
+}
+
+static void free_ws(lwp_context* h) {
+    PostWorkspace& w = h->ws;
+    void* ptrs[] = {w.peak_count, w.peak_key, w.peak_val, w.kpt_count, w.kpt_xy, w.kpt_score, w.conn_count,
+                    w.conn_ij, w.conn_ratio, w.flags, w.entries, w.n_entries, w.kpts_out};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    w = PostWorkspace();
+}
+
+extern "C" int lwp_destroy(lwp_handle h) {
+    if (!h) return LWP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (float* p : h->bufs) if (p) (void)hipFree(p);
+    for (float* p : h->d_outs) if (p) (void)hipFree(p);
+    if (h->d_in) (void)hipFree(h->d_in);
+    if (h->d_tmp) (void)hipFree(h->d_tmp);
+    if (h->d_tmp2) (void)hipFree(h->d_tmp2);
+    if (h->d_blob) (void)hipFree(h->d_blob);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    free_ws(h);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return LWP_OK;
+}
+
+extern "C" int lwp_set_capacity(lwp_handle h, int max_peaks, int max_kpts, int max_conn, int max_entries) {
+    if (!h) return LWP_ERR_ARG;
+    if (max_peaks < 64 || max_peaks > 8192 || max_kpts < 1 || max_kpts > 1024 || max_conn < 1 || max_conn > (1 << 20) ||
+        max_entries < 1 || max_entries > 640)
+        return fail(h, LWP_ERR_ARG, "capacity out of range (peaks 64..8192, kpts 1..1024, conns 1..2^20, entries 1..640)");
+    (void)hipSetDevice(h->device);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_ws(h);
+    h->caps.max_peaks = max_peaks; h->caps.max_kpts = max_kpts; h->caps.max_conn = max_conn; h->caps.max_entries = max_entries;
+    return LWP_OK;
+}
+
+extern "C" int lwp_load_weights(lwp_handle h, const char* const* names, const void* const* ptrs, const int64_t* shapes,
+                                const int* ndims, int n) {
+    if (!h || !names || !ptrs || !shapes || !ndims || n <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    std::vector<std::string> nm(n);
+    std::vector<HostTensor> ts(n);
+    for (int i = 0; i < n; ++i) {
+        nm[i] = names[i] ? names[i] : "";
+        ts[i].ptr = ptrs[i];
+        ts[i].ndim = ndims[i];
+        for (int d = 0; d < 4; ++d) ts[i].shape[d] = shapes[i * 4 + d];
+    }
+    std::vector<float> blob;
+    std::string msg = pack_weights(h->g, nm, ts, blob);
+    if (!msg.empty()) return fail(h, LWP_ERR_ARG, msg);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->weights_loaded = true;
+    return LWP_OK;
+}
+
+extern "C" int lwp_weights_blob_bytes(lwp_handle h, size_t* bytes) {
+    if (!h || !bytes) return LWP_ERR_ARG;
+    *bytes = h->g.blob_floats * sizeof(float);
+    return LWP_OK;
+}
+extern "C" int lwp_weights_blob_export(lwp_handle h, void* dst, size_t bytes) {
+    if (!h || !dst || bytes != h->g.blob_floats * sizeof(float)) return fail(h, LWP_ERR_ARG, "bad blob size");
+    if (!h->weights_loaded) return fail(h, LWP_ERR_STATE, "weights not loaded");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(dst, h->d_blob, bytes, hipMemcpyDeviceToDevice));
+    return LWP_OK;
+}
+extern "C" int lwp_weights_blob_import(lwp_handle h, const void* src, size_t bytes) {
+    if (!h || !src || bytes != h->g.blob_floats * sizeof(float)) return fail(h, LWP_ERR_ARG, "bad blob size");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(h->d_blob, src, bytes, hipMemcpyDeviceToDevice));
+    h->weights_loaded = true;
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- buffers
+static void level_dims(int H, int W, int level, int* h, int* w) {
+    int hh = H, ww = W;
+    for (int l = 0; l < level; ++l) { hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1; }
+    *h = hh; *w = ww;
+}
+
+static int ensure_activations(lwp_context* h, int N, int H, int W) {
+    if (h->cur_N == N && h->cur_H == H && h->cur_W == W) return LWP_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->bufs.size(); ++i) {
+        if (h->bufs[i]) { HIP_TRY(h, hipFree(h->bufs[i])); h->bufs[i] = nullptr; }
+        int bh, bw;
+        level_dims(H, W, h->g.bufs[i].level, &bh, &bw);
+        const size_t bytes = (size_t)N * bh * bw * h->g.bufs[i].channels * sizeof(float);
+        HIP_TRY(h, hipMalloc((void**)&h->bufs[i], bytes));
+        // the concat buffer's pad channels must hold finite values (their weights are zero)
+        HIP_TRY(h, hipMemsetAsync(h->bufs[i], 0, bytes, h->stream));
+    }
+    h->cur_N = N; h->cur_H = H; h->cur_W = W;
+    return LWP_OK;
+}
+
+static int ensure_ws(lwp_context* h, int N) {
+    PostWorkspace& w = h->ws;
+    if (w.N >= N && w.peak_count) return LWP_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    free_ws(h);
+    w.caps = h->caps;
+    const PostCaps& c = h->caps;
+#define WS_ALLOC(field, count, type) HIP_TRY(h, hipMalloc((void**)&w.field, (size_t)(count) * sizeof(type)))
+    WS_ALLOC(peak_count, N * 18, int);
+    WS_ALLOC(peak_key, (size_t)N * 18 * c.max_peaks, uint32_t);
+    WS_ALLOC(peak_val, (size_t)N * 18 * c.max_peaks, float);
+    WS_ALLOC(kpt_count, N * 18, int);
+    WS_ALLOC(kpt_xy, (size_t)N * 18 * c.max_kpts * 2, int);
+    WS_ALLOC(kpt_score, (size_t)N * 18 * c.max_kpts, float);
+    WS_ALLOC(conn_count, N * 19, int);
+    WS_ALLOC(conn_ij, (size_t)N * 19 * c.max_conn, int);
+    WS_ALLOC(conn_ratio, (size_t)N * 19 * c.max_conn, double);
+    WS_ALLOC(flags, (size_t)N * 4, unsigned long long);
+    WS_ALLOC(entries, (size_t)N * c.max_entries * 20, double);
+    WS_ALLOC(n_entries, N, int);
+    WS_ALLOC(kpts_out, (size_t)N * 18 * c.max_kpts * 4, double);
+#undef WS_ALLOC
+    w.N = N;
+    return LWP_OK;
+}
+
+static int ensure_host_stage(lwp_context* h, size_t bytes) {
+    if (h->h_stage_bytes >= bytes) return LWP_OK;
+    if (h->h_stage) HIP_TRY(h, hipHostFree(h->h_stage));
+    h->h_stage = nullptr; h->h_stage_bytes = 0;
+    HIP_TRY(h, hipHostMalloc(&h->h_stage, bytes, hipHostMallocDefault));
+    h->h_stage_bytes = bytes;
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- profiling hooks
+static int prof_begin(lwp_context* h, int kclass) {
+    if (!h->profiling) return LWP_OK;
+    if (h->ev_used + 2 > h->ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            HIP_TRY(h, hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        h->ev_class.resize(h->ev.size() / 2);
+    }
+    h->ev_class[h->ev_used / 2] = kclass;
+    HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], h->stream));
+    return LWP_OK;
+}
+static int prof_end(lwp_context* h) {
+    if (!h->profiling) return LWP_OK;
+    HIP_TRY(h, hipEventRecord(h->ev[h->ev_used + 1], h->stream));
+    h->ev_used += 2;
+    return LWP_OK;
+}
+#define LAUNCH(h, kclass, expr)                    \
+    do {                                           \
+        int rc_ = prof_begin(h, kclass);           \
+        if (rc_) return rc_;                       \
+        HIP_TRY(h, expr);                          \
+        rc_ = prof_end(h);                         \
+        if (rc_) return rc_;                       \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------- forward
+// enqueue every layer on the handle's stream.  d_outs_nchw: 2*(1+nref) device pointers or null.
+static int enqueue_forward(lwp_context* h, const float* d_in, int N, int H, int W, float* const* d_outs_nchw,
+                           int max_layers = 1 << 30) {
+    const Graph& g = h->g;
+    int li = 0;
+    for (const Layer& l : g.layers) {
+        if (li++ >= max_layers) break;
+        const float* wts = h->d_blob + l.w_off;
+        const float* bias = h->d_blob + l.b_off;
+        int dh, dw;
+        level_dims(H, W, g.bufs[l.dst.buf].level, &dh, &dw);
+        float* dst = h->bufs[l.dst.buf] + l.dst.coff;
+        if (l.kind == L_STEM) {
+            StemParams p{d_in, wts, bias, dst, N, H, W, dh, dw};
+            LAUNCH(h, KC_STEM, launch_stem(p, h->stream));
+        } else if (l.kind == L_DW) {
+            int sh, sw;
+            level_dims(H, W, g.bufs[l.src.buf].level, &sh, &sw);
+            DwParams p{h->bufs[l.src.buf] + l.src.coff, l.src.ld, wts, bias, dst, l.dst.ld, N, sh, sw, dh, dw, l.cin, l.stride, l.dil, l.act};
+            LAUNCH(h, KC_DW, launch_dw(p, h->stream));
+        } else {
+            GemmParams p;
+            p.in = h->bufs[l.src.buf] + l.src.coff; p.in_ld = l.src.ld;
+            p.w = wts; p.bias = bias;
+            p.out = dst; p.out_ld = l.dst.ld;
+            p.res = l.res.buf >= 0 ? h->bufs[l.res.buf] + l.res.coff : nullptr; p.res_ld = l.res.ld;
+            p.out_nchw = (l.out_index >= 0 && d_outs_nchw) ? d_outs_nchw[l.out_index] : nullptr;
+            p.N = N; p.H = dh; p.W = dw;
+            p.cin_pad = l.cin_pad; p.cout = l.cout; p.cout_pad = l.cout_pad; p.ks = l.ks; p.dil = l.dil; p.act = l.act;
+            LAUNCH(h, l.ks == 1 ? KC_PW : KC_C3, launch_gemm(p, h->stream));
+        }
+    }
+    return LWP_OK;
+}
+
+static int check_frame_shape(lwp_context* h, int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return fail(h, LWP_ERR_ARG, "bad frame shape");
+    if (H % 8 || W % 8) return fail(h, LWP_ERR_ARG, "H and W must be multiples of the network stride (8)");
+    if (!h->weights_loaded) return fail(h, LWP_ERR_STATE, "weights not loaded (call lwp_load_weights first)");
+    return LWP_OK;
+}
+
+static int stage_input(lwp_context* h, const float* in, int in_mem, size_t bytes, const float** d_in) {
+    if (in_mem == LWP_MEM_DEVICE) { *d_in = in; return LWP_OK; }
+    int rc = ensure_dev(h, &h->d_in, &h->d_in_bytes, bytes);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->d_in, in, bytes, hipMemcpyHostToDevice, h->stream));
+    *d_in = h->d_in;
+    return LWP_OK;
+}
+
+extern "C" int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int H, int W, float* const* outs, int out_mem) {
+    if (!h || !in || !outs) return fail(h, LWP_ERR_ARG, "null argument");
+    int rc = check_frame_shape(h, N, H, W);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = ensure_activations(h, N, H, W);
+    if (rc) return rc;
+    const float* d_in = nullptr;
+    rc = stage_input(h, in, in_mem, (size_t)N * 3 * H * W * sizeof(float), &d_in);
+    if (rc) return rc;
+    const int nout = 2 * (1 + h->g.nref);
+    const int fh = H / 8, fw = W / 8;
+    std::vector<float*> d_outs(nout);
+    for (int i = 0; i < nout; ++i) {
+        if (!outs[i]) return fail(h, LWP_ERR_ARG, "null output pointer");
+        if (out_mem == LWP_MEM_DEVICE) { d_outs[i] = outs[i]; continue; }
+        const size_t bytes = (size_t)N * (i % 2 ? h->g.NP : h->g.NH) * fh * fw * sizeof(float);
+        rc = ensure_dev(h, &h->d_outs[i], &h->d_outs_bytes[i], bytes);
+        if (rc) return rc;
+        d_outs[i] = h->d_outs[i];
+    }
+    rc = enqueue_forward(h, d_in, N, H, W, d_outs.data());
+    if (rc) return rc;
+    if (out_mem == LWP_MEM_HOST) {
+        for (int i = 0; i < nout; ++i) {
+            const size_t bytes = (size_t)N * (i % 2 ? h->g.NP : h->g.NH) * fh * fw * sizeof(float);
+            HIP_TRY(h, hipMemcpyAsync(outs[i], d_outs[i], bytes, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- upsample
+extern "C" int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, int C, int hs, int ws, int ratio, float* dst, int dst_mem) {
+    if (!h || !src || !dst || N <= 0 || C <= 0 || hs <= 0 || ws <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    if (ratio != 4 && ratio != 8) return fail(h, LWP_ERR_ARG, "upsample ratio must be 4 or 8");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t sb = (size_t)N * C * hs * ws * sizeof(float), db = sb * ratio * ratio;
+    const float* d_src = src;
+    if (src_mem == LWP_MEM_HOST) {
+        int rc = ensure_dev(h, &h->d_tmp, &h->d_tmp_bytes, sb);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp, src, sb, hipMemcpyHostToDevice, h->stream));
+        d_src = h->d_tmp;
+    }
+    float* d_dst = dst;
+    if (dst_mem == LWP_MEM_HOST) {
+        int rc = ensure_dev(h, &h->d_tmp2, &h->d_tmp2_bytes, db);
+        if (rc) return rc;
+        d_dst = h->d_tmp2;
+    }
+    MapView v{d_src, (int64_t)C * hs * ws, (int64_t)ws, 1, (int64_t)hs * ws, hs, ws};
+    LAUNCH(h, KC_POST, launch_upsample(v, N, C, ratio, d_dst, h->stream));
+    if (dst_mem == LWP_MEM_HOST) {
+        HIP_TRY(h, hipMemcpyAsync(dst, d_dst, db, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- extract_keypoints
+extern "C" int lwp_extract_keypoints(lwp_handle h, float* heatmap, int H, int W, int64_t row_stride, int64_t pix_stride,
+                                     int64_t* xs, int64_t* ys, float* scores, int cap, int* count) {
+    if (!h || !heatmap || !xs || !ys || !scores || !count || H <= 0 || W <= 0 || cap < 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    if (H > 65535 || W > 65535) return fail(h, LWP_ERR_ARG, "map too large");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_ws(h, 1);
+    if (rc) return rc;
+    const size_t bytes = (size_t)H * W * sizeof(float);
+    rc = ensure_host_stage(h, bytes + (size_t)h->caps.max_kpts * 12 + 64);
+    if (rc) return rc;
+    rc = ensure_dev(h, &h->d_tmp, &h->d_tmp_bytes, bytes);
+    if (rc) return rc;
+    float* hs = (float*)h->h_stage;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) hs[(size_t)y * W + x] = heatmap[y * row_stride + x * pix_stride];
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp, hs, bytes, hipMemcpyHostToDevice, h->stream));
+    LAUNCH(h, KC_POST, launch_reset_ws(1, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_threshold_inplace(h->d_tmp, (int64_t)H * W, h->stream));
+    MapView v{h->d_tmp, 0, (int64_t)W, 1, 0, H, W};
+    LAUNCH(h, KC_POST, launch_find_peaks(v, 1, 1, 1, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_nms(1, 1, H, h->ws, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(hs, h->d_tmp, bytes, hipMemcpyDeviceToHost, h->stream));
+    int* h_xy = (int*)((char*)h->h_stage + bytes);
+    float* h_sc = (float*)(h_xy + (size_t)h->caps.max_kpts * 2);
+    int n = 0;
+    unsigned long long fl = 0;
+    HIP_TRY(h, hipMemcpyAsync(h_xy, h->ws.kpt_xy, (size_t)h->caps.max_kpts * 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_sc, h->ws.kpt_score, (size_t)h->caps.max_kpts * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&n, h->ws.kpt_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&fl, h->ws.flags, sizeof(fl), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) heatmap[y * row_stride + x * pix_stride] = hs[(size_t)y * W + x];
+    if (fl & 3ull) return fail(h, LWP_ERR_CAPACITY, "extract_keypoints: peak or key-point capacity exceeded (lwp_set_capacity)");
+    if (n > cap) return fail(h, LWP_ERR_CAPACITY, "extract_keypoints: output arrays too small");
+    for (int i = 0; i < n; ++i) { xs[i] = h_xy[2 * i]; ys[i] = h_xy[2 * i + 1]; scores[i] = h_sc[i]; }
+    *count = n;
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- results
+static int fetch_results(lwp_context* h, int N, int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap, int* n_entries) {
+    const PostCaps& c = h->ws.caps;
+    const size_t b_cnt = (size_t)N * 18 * sizeof(int), b_ne = (size_t)N * sizeof(int), b_fl = (size_t)N * 4 * 8;
+    const size_t b_k = (size_t)N * 18 * c.max_kpts * 4 * sizeof(double), b_e = (size_t)N * c.max_entries * 20 * sizeof(double);
+    int rc = ensure_host_stage(h, b_cnt + b_ne + b_fl + b_k + b_e + 64);
+    if (rc) return rc;
+    char* p = (char*)h->h_stage;
+    unsigned long long* h_fl = (unsigned long long*)p; p += b_fl;
+    double* h_k = (double*)p; p += b_k;
+    double* h_e = (double*)p; p += b_e;
+    int* h_cnt = (int*)p; p += b_cnt;
+    int* h_ne = (int*)p;
+    HIP_TRY(h, hipMemcpyAsync(h_fl, h->ws.flags, b_fl, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_cnt, h->ws.kpt_count, b_cnt, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_ne, h->ws.n_entries, b_ne, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_k, h->ws.kpts_out, b_k, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_e, h->ws.entries, b_e, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int f = 0; f < N; ++f) {
+        if (h_fl[f * 4 + 0]) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "frame %d: post-processing capacity exceeded (bits 0x%llx: 1 peaks, 2 key-points, 4 connections/entries)", f, h_fl[f * 4]);
+            return fail(h, LWP_ERR_CAPACITY, msg);
+        }
+        if (h_fl[f * 4 + 1] < h_fl[f * 4 + 2])
+            return fail(h, LWP_ERR_UNBOUND, "local variable 'ratio' referenced before assignment");
+        int total = 0;
+        for (int t = 0; t < 18; ++t) { kpt_counts[f * 18 + t] = h_cnt[f * 18 + t]; total += h_cnt[f * 18 + t]; }
+        if (total > kpt_cap || h_ne[f] > entry_cap) return fail(h, LWP_ERR_CAPACITY, "result arrays too small");
+        std::memcpy(kpts + (size_t)f * kpt_cap * 4, h_k + (size_t)f * 18 * c.max_kpts * 4, (size_t)total * 4 * sizeof(double));
+        std::memcpy(entries + (size_t)f * entry_cap * 20, h_e + (size_t)f * c.max_entries * 20, (size_t)h_ne[f] * 20 * sizeof(double));
+        n_entries[f] = h_ne[f];
+    }
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- group_keypoints
+extern "C" int lwp_group_keypoints(lwp_handle h, const double* kpts, const int* type_counts, const float* pafs, int pafs_mem,
+                                   int H, int W, int demo, double* pose_entries, int cap_entries, int* n_entries) {
+    if (!h || !type_counts || !pafs || !pose_entries || !n_entries || H <= 0 || W <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_ws(h, 1);
+    if (rc) return rc;
+    const PostCaps& c = h->ws.caps;
+    int total = 0;
+    for (int t = 0; t < 18; ++t) {
+        if (type_counts[t] < 0) return fail(h, LWP_ERR_ARG, "negative type count");
+        if (type_counts[t] > c.max_kpts) return fail(h, LWP_ERR_CAPACITY, "group_keypoints: more key-points of one type than max_kpts_per_type");
+        total += type_counts[t];
+    }
+    if (total > 0 && !kpts) return fail(h, LWP_ERR_ARG, "kpts is null");
+    std::vector<int> xy((size_t)18 * c.max_kpts * 2, 0), cnt(18);
+    std::vector<float> sc((size_t)18 * c.max_kpts, 0.f);
+    int r = 0;
+    for (int t = 0; t < 18; ++t) {
+        cnt[t] = type_counts[t];
+        for (int i = 0; i < type_counts[t]; ++i, ++r) {
+            const double x = kpts[r * 4], y = kpts[r * 4 + 1];
+            if (!(x >= 0 && x < W && y >= 0 && y < H)) return fail(h, LWP_ERR_ARG, "key-point outside the PAF map");
+            if (kpts[r * 4 + 3] != (double)r) return fail(h, LWP_ERR_ARG, "key-point ids must be the running index 0..K-1");
+            xy[((size_t)t * c.max_kpts + i) * 2] = (int)x;
+            xy[((size_t)t * c.max_kpts + i) * 2 + 1] = (int)y;
+            sc[(size_t)t * c.max_kpts + i] = (float)kpts[r * 4 + 2];
+        }
+    }
+    const int NPc = h->g.NP;
+    const float* d_paf = pafs;
+    if (pafs_mem == LWP_MEM_HOST) {
+        const size_t pb = (size_t)H * W * NPc * sizeof(float);
+        rc = ensure_dev(h, &h->d_tmp2, &h->d_tmp2_bytes, pb);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp2, pafs, pb, hipMemcpyHostToDevice, h->stream));
+        d_paf = h->d_tmp2;
+    }
+    LAUNCH(h, KC_POST, launch_reset_ws(1, h->ws, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->ws.kpt_xy, xy.data(), xy.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->ws.kpt_score, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->ws.kpt_count, cnt.data(), 18 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));   // the host vectors above go out of scope
+    MapView v{d_paf, 0, (int64_t)W * NPc, (int64_t)NPc, 1, H, W};
+    LAUNCH(h, KC_POST, launch_score_pairs(v, 1, 1, demo, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_assemble(1, h->ws, h->stream));
+    std::vector<int> kc(18);
+    std::vector<double> kout((size_t)std::max(total, 1) * 4);
+    return fetch_results(h, 1, kc.data(), kout.data(), std::max(total, 1), pose_entries, cap_entries, n_entries);
+}
+
+// ---------------------------------------------------------------------------------------------- fused pipeline
+static int enqueue_poses(lwp_context* h, const float* d_in, int N, int H, int W, int ratio, int demo, bool with_post) {
+    int rc = enqueue_forward(h, d_in, N, H, W, nullptr);
+    if (rc || !with_post) return rc;
+    const Graph& g = h->g;
+    const int fh = H / 8, fw = W / 8, cc = g.cat_channels;
+    const float* cat = h->bufs[g.cat_buf];
+    MapView heat{cat + g.C, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
+    MapView paf{cat + g.C + g.NH, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
+    LAUNCH(h, KC_POST, launch_reset_ws(N, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_find_peaks(heat, N, 18, ratio, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_nms(N, 18, fh * ratio, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_score_pairs(paf, N, ratio, demo, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_assemble(N, h->ws, h->stream));
+    return LWP_OK;
+}
+
+static int prepare_poses(lwp_context* h, int N, int H, int W, int ratio) {
+    int rc = check_frame_shape(h, N, H, W);
+    if (rc) return rc;
+    if (ratio != 4 && ratio != 8) return fail(h, LWP_ERR_ARG, "upsample ratio must be 4 or 8");
+    if (h->g.NH < 18 || h->g.NP < 38) return fail(h, LWP_ERR_ARG, "pose grouping needs >= 18 heat-maps and >= 38 PAFs");
+    if ((int64_t)H / 8 * ratio > 65535 || (int64_t)W / 8 * ratio > 65535) return fail(h, LWP_ERR_ARG, "map too large");
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = ensure_activations(h, N, H, W);
+    if (rc) return rc;
+    return ensure_ws(h, N);
+}
+
+extern "C" int lwp_infer_poses_async(lwp_handle h, const float* in_device, int N, int H, int W, int ratio, int demo) {
+    if (!h || !in_device) return fail(h, LWP_ERR_ARG, "null argument");
+    int rc = prepare_poses(h, N, H, W, ratio);
+    if (rc) return rc;
+    h->last_N = N;
+    return enqueue_poses(h, in_device, N, H, W, ratio, demo, true);
+}
+
+extern "C" int lwp_fetch_poses(lwp_handle h, int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap, int* n_entries) {
+    if (!h || !kpt_counts || !kpts || !entries || !n_entries) return fail(h, LWP_ERR_ARG, "null argument");
+    if (h->last_N <= 0) return fail(h, LWP_ERR_STATE, "no pipeline run to fetch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return fetch_results(h, h->last_N, kpt_counts, kpts, kpt_cap, entries, entry_cap, n_entries);
+}
+
+extern "C" int lwp_infer_poses(lwp_handle h, const float* in, int in_mem, int N, int H, int W, int ratio, int demo,
+                               int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap, int* n_entries) {
+    if (!h || !in || !kpt_counts || !kpts || !entries || !n_entries) return fail(h, LWP_ERR_ARG, "null argument");
+    int rc = prepare_poses(h, N, H, W, ratio);
+    if (rc) return rc;
+    const float* d_in = nullptr;
+    rc = stage_input(h, in, in_mem, (size_t)N * 3 * H * W * sizeof(float), &d_in);
+    if (rc) return rc;
+    h->last_N = N;
+    rc = enqueue_poses(h, d_in, N, H, W, ratio, demo, true);
+    if (rc) return rc;
+    return fetch_results(h, N, kpt_counts, kpts, kpt_cap, entries, entry_cap, n_entries);
+}
+
+extern "C" int lwp_poses_from_maps(lwp_handle h, const float* heat, const float* paf, int mem, int N, int hs, int ws, int ratio,
+                                   int demo, int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap,
+                                   int* n_entries) {
+    if (!h || !heat || !paf || !kpt_counts || !kpts || !entries || !n_entries || N <= 0 || hs <= 0 || ws <= 0)
+        return fail(h, LWP_ERR_ARG, "bad argument");
+    if (ratio != 4 && ratio != 8 && ratio != 1) return fail(h, LWP_ERR_ARG, "upsample ratio must be 1, 4 or 8");
+    if (h->g.NH < 18 || h->g.NP < 38) return fail(h, LWP_ERR_ARG, "pose grouping needs >= 18 heat-maps and >= 38 PAFs");
+    if ((int64_t)hs * ratio > 65535 || (int64_t)ws * ratio > 65535) return fail(h, LWP_ERR_ARG, "map too large");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_ws(h, N);
+    if (rc) return rc;
+    const size_t hb = (size_t)N * h->g.NH * hs * ws * sizeof(float), pb = (size_t)N * h->g.NP * hs * ws * sizeof(float);
+    const float *d_heat = heat, *d_paf = paf;
+    if (mem == LWP_MEM_HOST) {
+        rc = ensure_dev(h, &h->d_tmp, &h->d_tmp_bytes, hb);
+        if (rc) return rc;
+        rc = ensure_dev(h, &h->d_tmp2, &h->d_tmp2_bytes, pb);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp, heat, hb, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp2, paf, pb, hipMemcpyHostToDevice, h->stream));
+        d_heat = h->d_tmp; d_paf = h->d_tmp2;
+    }
+    const int64_t hw = (int64_t)hs * ws;
+    MapView hv{d_heat, (int64_t)h->g.NH * hw, (int64_t)ws, 1, hw, hs, ws};
+    MapView pv{d_paf, (int64_t)h->g.NP * hw, (int64_t)ws, 1, hw, hs, ws};
+    LAUNCH(h, KC_POST, launch_reset_ws(N, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_find_peaks(hv, N, 18, ratio, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_nms(N, 18, hs * ratio, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_score_pairs(pv, N, ratio, demo, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_assemble(N, h->ws, h->stream));
+    h->last_N = N;
+    return fetch_results(h, N, kpt_counts, kpts, kpt_cap, entries, entry_cap, n_entries);
+}
+
+// ---------------------------------------------------------------------------------------------- introspection
+extern "C" int lwp_layer_count(lwp_handle h) { return h ? (int)h->g.layers.size() : LWP_ERR_ARG; }
+
+extern "C" int lwp_layer_info(lwp_handle h, int idx, char* name, int name_cap, int* kind, int* cin, int* cout, int* ks,
+                              int* stride, int* dil) {
+    if (!h || idx < 0 || idx >= (int)h->g.layers.size() || !name) return fail(h, LWP_ERR_ARG, "bad argument");
+    const Layer& l = h->g.layers[idx];
+    if ((int)l.name.size() + 1 > name_cap) return fail(h, LWP_ERR_ARG, "name buffer too small");
+    std::strcpy(name, l.name.c_str());
+    if (kind) *kind = l.kind;
+    if (cin) *cin = l.cin;
+    if (cout) *cout = l.cout;
+    if (ks) *ks = l.ks;
+    if (stride) *stride = l.stride;
+    if (dil) *dil = l.dil;
+    return LWP_OK;
+}
+
+extern "C" int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int H, int W, int idx, float* dst, size_t dst_floats,
+                                      int out_dims[4]) {
+    if (!h || !in || !dst || !out_dims || idx < 0 || idx >= (int)h->g.layers.size()) return fail(h, LWP_ERR_ARG, "bad argument");
+    int rc = check_frame_shape(h, N, H, W);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = ensure_activations(h, N, H, W);
+    if (rc) return rc;
+    const float* d_in = nullptr;
+    rc = stage_input(h, in, LWP_MEM_HOST, (size_t)N * 3 * H * W * sizeof(float), &d_in);
+    if (rc) return rc;
+    rc = enqueue_forward(h, d_in, N, H, W, nullptr, idx + 1);
+    if (rc) return rc;
+    const Layer& l = h->g.layers[idx];
+    int dh, dw;
+    level_dims(H, W, h->g.bufs[l.dst.buf].level, &dh, &dw);
+    const size_t n = (size_t)N * l.cout * dh * dw;
+    if (dst_floats < n) return fail(h, LWP_ERR_ARG, "dst too small");
+    rc = ensure_dev(h, &h->d_tmp, &h->d_tmp_bytes, n * sizeof(float));
+    if (rc) return rc;
+    // NHWC window (ld, coff) -> compact NCHW
+    HIP_TRY(h, launch_nchw_from_nhwc(h->bufs[l.dst.buf] + l.dst.coff, l.dst.ld, h->d_tmp, N, dh * dw, l.cout, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dst, h->d_tmp, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    out_dims[0] = N; out_dims[1] = l.cout; out_dims[2] = dh; out_dims[3] = dw;
+    return LWP_OK;
+}
+
+extern "C" int lwp_synchronize(lwp_handle h) {
+    if (!h) return LWP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- measurement
+extern "C" int lwp_time_pipeline(lwp_handle h, const float* in_device, int N, int H, int W, int ratio, int demo, int what,
+                                 int iters, float* ms_total) {
+    if (!h || !in_device || !ms_total || iters <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    int rc = prepare_poses(h, N, H, W, ratio);
+    if (rc) return rc;
+    h->last_N = N;
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < iters; ++i) {
+        rc = enqueue_poses(h, in_device, N, H, W, ratio, demo, what != 0);
+        if (rc) return rc;
+    }
+    HIP_TRY(h, hipEventRecord(e1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(e1));
+    HIP_TRY(h, hipEventElapsedTime(ms_total, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return LWP_OK;
+}
+
+extern "C" int lwp_profile_classes(lwp_handle h, const float* in_device, int N, int H, int W, int ratio, int demo, int reps,
+                                   float* ms, int* launches) {
+    if (!h || !in_device || !ms || !launches || reps <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    int rc = prepare_poses(h, N, H, W, ratio);
+    if (rc) return rc;
+    h->last_N = N;
+    for (int k = 0; k < KC_COUNT; ++k) { ms[k] = 0.f; launches[k] = 0; }
+    for (int r = 0; r < reps; ++r) {
+        h->profiling = true;
+        h->ev_used = 0;
+        rc = enqueue_poses(h, in_device, N, H, W, ratio, demo, true);
+        h->profiling = false;
+        if (rc) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i + 1 < h->ev_used + 1 && i < h->ev_used; i += 2) {
+            float t = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+            const int k = h->ev_class[i / 2];
+            ms[k] += t;
+            if (r == 0) launches[k] += 1;
+        }
+    }
+    for (int k = 0; k < KC_COUNT; ++k) ms[k] /= (float)reps;
+    return LWP_OK;
+}

@@ -1,0 +1,137 @@
+// Internal declarations shared by the host graph code, the HIP kernels and the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/lwpose.h"
+
+namespace lwp {
+
+// ------------------------------------------------------------------ parameter table
+struct ParamSpec {
+    std::string key;
+    int64_t shape[4];
+    int ndim;
+    int role;
+};
+std::vector<ParamSpec> param_table(int nref, int C, int NH, int NP);
+
+// ------------------------------------------------------------------ layer graph
+enum LayerKind { L_STEM = 0, L_DW = 1, L_GEMM = 2 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2 };
+enum KClass { KC_STEM = 0, KC_DW = 1, KC_PW = 2, KC_C3 = 3, KC_POST = 4, KC_OTHER = 5, KC_COUNT = 6 };
+
+struct BufRef {      // a channel window of an NHWC activation buffer
+    int buf = -1;    // index into Graph::bufs
+    int coff = 0;    // first channel
+    int ld = 0;      // row stride (channels per pixel) the layer addresses the buffer with
+};
+
+struct Layer {
+    int kind = L_GEMM;
+    std::string name;          // e.g. "model.3.pw"
+    std::string conv_key;      // state_dict prefix of the conv ("model.3.3")
+    std::string bn_key;        // state_dict prefix of the BN ("" = none)
+    bool has_bias = false;
+    int cin = 0, cout = 0, ks = 1, stride = 1, dil = 1, act = ACT_NONE;
+    BufRef src, dst, res;      // res.buf < 0: no residual
+    int out_index = -1;        // >= 0: this layer also produces stage output #out_index (NCHW)
+    // packed weights (float offsets into the blob)
+    size_t w_off = 0, b_off = 0;
+    int cin_pad = 0, cout_pad = 0;
+};
+
+struct BufSpec {
+    int level;      // spatial level: 1 = H/2, 2 = H/4, 3 = H/8
+    int channels;   // capacity in channels per pixel (layers may address it with a smaller ld)
+};
+
+struct Graph {
+    int nref, C, NH, NP;
+    std::vector<BufSpec> bufs;
+    std::vector<Layer> layers;
+    size_t blob_floats = 0;
+    int cat_buf = -1;          // the [feat | heat | paf | pad] buffer
+    int cat_channels = 0;
+};
+Graph build_graph(int nref, int C, int NH, int NP);
+
+struct HostTensor {
+    const void* ptr;
+    int64_t shape[4];
+    int ndim;
+};
+// folds BN, packs into `blob` (size g.blob_floats); returns "" or an error message
+std::string pack_weights(const Graph& g, const std::vector<std::string>& names,
+                         const std::vector<HostTensor>& tensors, std::vector<float>& blob);
+
+// ------------------------------------------------------------------ kernel launch parameters
+struct StemParams {
+    const float* in;     // N x 3 x H x W
+    const float* w;      // [27][32]  (ky, kx, ci) major, oc minor
+    const float* bias;   // [32]
+    float* out;          // N x Ho x Wo x 32
+    int N, H, W, Ho, Wo;
+};
+struct DwParams {
+    const float* in; int in_ld;      // NHWC, row stride in_ld
+    const float* w;                  // [9][C]
+    const float* bias;               // [C]
+    float* out; int out_ld;
+    int N, Hi, Wi, Ho, Wo, C, stride, dil, act;
+};
+struct GemmParams {
+    const float* in; int in_ld;      // window start already applied to the pointer
+    const float* w;                  // [taps][cout_pad][cin_pad]
+    const float* bias;               // [cout_pad]
+    float* out; int out_ld;
+    const float* res; int res_ld;    // may be null
+    float* out_nchw;                 // may be null: N x cout x H x W
+    int N, H, W, cin_pad, cout, cout_pad, ks, dil, act;
+};
+hipError_t launch_stem(const StemParams& p, hipStream_t s);
+hipError_t launch_dw(const DwParams& p, hipStream_t s);
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+
+// ------------------------------------------------------------------ post-processing
+struct MapView {          // a float32 map set addressed as base[n*ns + y*ys + x*xs + c*cs]
+    const float* base;
+    int64_t ns, ys, xs, cs;
+    int h, w;             // size of the stored grid
+};
+struct PostCaps { int max_peaks = 2048, max_kpts = 128, max_conn = 4096, max_entries = 256; };
+
+struct PostWorkspace {    // device buffers, sized for (N frames, caps)
+    int N = 0;
+    PostCaps caps;
+    int* peak_count = nullptr;      // [N*18]
+    uint32_t* peak_key = nullptr;   // [N*18*max_peaks]  (x << 16 | y)
+    float* peak_val = nullptr;      // [N*18*max_peaks]
+    int* kpt_count = nullptr;       // [N*18]
+    int* kpt_xy = nullptr;          // [N*18*max_kpts*2]
+    float* kpt_score = nullptr;     // [N*18*max_kpts]
+    int* conn_count = nullptr;      // [N*19]
+    int* conn_ij = nullptr;         // [N*19*max_conn]   (i << 16 | j)
+    double* conn_ratio = nullptr;   // [N*19*max_conn]
+    unsigned long long* flags = nullptr;  // [N*4]  0: overflow bits (1 peaks, 2 kpts, 4 conns/entries),
+                                          //        1: min order of a pair whose mid-point test failed,
+                                          //        2: min order of a pair whose mid-point test passed
+    double* entries = nullptr;      // [N*max_entries*20]
+    int* n_entries = nullptr;       // [N]
+    double* kpts_out = nullptr;     // [N*18*max_kpts*4]
+};
+
+hipError_t init_cubic_tables();
+hipError_t launch_reset_ws(int N, PostWorkspace& ws, hipStream_t s);
+hipError_t launch_upsample(const MapView& src, int N, int C, int ratio, float* dst, hipStream_t s);
+// threshold + strict 4-neighbour maximum on the (virtually) up-sampled heat-maps; ratio == 1: src is already full-res
+hipError_t launch_find_peaks(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s);
+hipError_t launch_nms(int N, int ntypes, int Hfull, PostWorkspace& ws, hipStream_t s);
+hipError_t launch_score_pairs(const MapView& paf, int N, int ratio, int demo, PostWorkspace& ws, hipStream_t s);
+hipError_t launch_assemble(int N, PostWorkspace& ws, hipStream_t s);
+hipError_t launch_threshold_inplace(float* map, int64_t n, hipStream_t s);
+hipError_t launch_nchw_from_nhwc(const float* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s);
+
+}  // namespace lwp

@@ -1,0 +1,255 @@
+// Host side of the network: parameter table, layer graph, BN folding and weight packing.
+//
+// Mirrors the structure of the reference network (models/with_mobilenet.py:89-123, built from
+// modules/conv.py:4-32) as a flat list of three kernel kinds on NHWC activations:
+//   L_STEM  3x3 stride-2 conv 3->32 (+BN+ReLU)                    with_mobilenet.py:93
+//   L_DW    depthwise 3x3 (+BN+ReLU | +ELU), stride 1/2, dil 1/2  conv.py:15-17, 27-28
+//   L_GEMM  1x1 or dense 3x3 conv as an implicit GEMM, bias/BN folded, ReLU|ELU|none,
+//           optional residual add after the activation             conv.py:4-10,19-21,30-31
+// torch.cat([features, heat, paf]) (with_mobilenet.py:121) is free: the producing layers write
+// channel windows of one [C | NH | NP | pad] buffer.
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "lwp_internal.h"
+
+namespace lwp {
+
+static const int kBackbone[11][4] = {  // cin, cout, stride, dilation (with_mobilenet.py:94-104)
+    {32, 64, 1, 1},   {64, 128, 2, 1},  {128, 128, 1, 1}, {128, 256, 2, 1}, {256, 256, 1, 1}, {256, 512, 1, 1},
+    {512, 512, 1, 2}, {512, 512, 1, 1}, {512, 512, 1, 1}, {512, 512, 1, 1}, {512, 512, 1, 1}};
+
+static std::string fmt(const char* f, int a = 0, int b = 0) {
+    char buf[128];
+    snprintf(buf, sizeof buf, f, a, b);
+    return buf;
+}
+
+static void add_conv(std::vector<ParamSpec>& t, const std::string& p, int cin, int cout, int k, int groups, bool bias) {
+    ParamSpec w{p + ".weight", {cout, cin / groups, k, k}, 4, LWP_ROLE_CONV_W};
+    t.push_back(w);
+    if (bias) t.push_back(ParamSpec{p + ".bias", {cout, 1, 1, 1}, 1, LWP_ROLE_CONV_B});
+}
+static void add_bn(std::vector<ParamSpec>& t, const std::string& p, int c) {
+    t.push_back(ParamSpec{p + ".weight", {c, 1, 1, 1}, 1, LWP_ROLE_BN_W});
+    t.push_back(ParamSpec{p + ".bias", {c, 1, 1, 1}, 1, LWP_ROLE_BN_B});
+    t.push_back(ParamSpec{p + ".running_mean", {c, 1, 1, 1}, 1, LWP_ROLE_BN_MEAN});
+    t.push_back(ParamSpec{p + ".running_var", {c, 1, 1, 1}, 1, LWP_ROLE_BN_VAR});
+    t.push_back(ParamSpec{p + ".num_batches_tracked", {1, 1, 1, 1}, 0, LWP_ROLE_BN_NBT});
+}
+
+std::vector<ParamSpec> param_table(int nref, int C, int NH, int NP) {
+    std::vector<ParamSpec> t;
+    add_conv(t, "model.0.0", 3, 32, 3, 1, false);
+    add_bn(t, "model.0.1", 32);
+    for (int i = 0; i < 11; ++i) {
+        int cin = kBackbone[i][0], cout = kBackbone[i][1];
+        add_conv(t, fmt("model.%d.0", i + 1), cin, cin, 3, cin, false);
+        add_bn(t, fmt("model.%d.1", i + 1), cin);
+        add_conv(t, fmt("model.%d.3", i + 1), cin, cout, 1, 1, false);
+        add_bn(t, fmt("model.%d.4", i + 1), cout);
+    }
+    add_conv(t, "cpm.align.0", 512, C, 1, 1, true);
+    for (int j = 0; j < 3; ++j) {
+        add_conv(t, fmt("cpm.trunk.%d.0", j), C, C, 3, C, false);
+        add_conv(t, fmt("cpm.trunk.%d.2", j), C, C, 1, 1, false);
+    }
+    add_conv(t, "cpm.conv.0", C, C, 3, 1, true);
+    for (int j = 0; j < 3; ++j) add_conv(t, fmt("initial_stage.trunk.%d.0", j), C, C, 3, 1, true);
+    add_conv(t, "initial_stage.heatmaps.0.0", C, 512, 1, 1, true);
+    add_conv(t, "initial_stage.heatmaps.1.0", 512, NH, 1, 1, true);
+    add_conv(t, "initial_stage.pafs.0.0", C, 512, 1, 1, true);
+    add_conv(t, "initial_stage.pafs.1.0", 512, NP, 1, 1, true);
+    for (int k = 0; k < nref; ++k) {
+        for (int b = 0; b < 5; ++b) {
+            int cin = b == 0 ? C + NH + NP : C;
+            std::string q = fmt("refinement_stages.%d.trunk.%d", k, b);
+            add_conv(t, q + ".initial.0", cin, C, 1, 1, true);
+            add_conv(t, q + ".trunk.0.0", C, C, 3, 1, true);
+            add_bn(t, q + ".trunk.0.1", C);
+            add_conv(t, q + ".trunk.1.0", C, C, 3, 1, true);
+            add_bn(t, q + ".trunk.1.1", C);
+        }
+        std::string p = fmt("refinement_stages.%d", k);
+        add_conv(t, p + ".heatmaps.0.0", C, C, 1, 1, true);
+        add_conv(t, p + ".heatmaps.1.0", C, NH, 1, 1, true);
+        add_conv(t, p + ".pafs.0.0", C, C, 1, 1, true);
+        add_conv(t, p + ".pafs.1.0", C, NP, 1, 1, true);
+    }
+    return t;
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+namespace {
+struct Builder {
+    Graph g;
+    int new_buf(int level, int ch) {
+        g.bufs.push_back(BufSpec{level, ch});
+        return (int)g.bufs.size() - 1;
+    }
+    static BufRef ref(int buf, int ld, int coff = 0) {
+        BufRef r;
+        r.buf = buf; r.ld = ld; r.coff = coff;
+        return r;
+    }
+    Layer& add(int kind, const std::string& name, const std::string& conv, const std::string& bn, bool bias,
+               int cin, int cout, int ks, int stride, int dil, int act, BufRef src, BufRef dst) {
+        Layer l;
+        l.kind = kind; l.name = name; l.conv_key = conv; l.bn_key = bn; l.has_bias = bias;
+        l.cin = cin; l.cout = cout; l.ks = ks; l.stride = stride; l.dil = dil; l.act = act;
+        l.src = src; l.dst = dst;
+        g.layers.push_back(l);
+        return g.layers.back();
+    }
+};
+}  // namespace
+
+Graph build_graph(int nref, int C, int NH, int NP) {
+    Builder b;
+    Graph& g = b.g;
+    g.nref = nref; g.C = C; g.NH = NH; g.NP = NP;
+    // level-1/2 buffers are single-use; level 3 ping-pongs two 512-channel slots and three C-channel slots
+    int s1 = b.new_buf(1, 32), d1 = b.new_buf(1, 32), p1 = b.new_buf(1, 64);
+    int d2 = b.new_buf(2, 64), p2 = b.new_buf(2, 128), d3 = b.new_buf(2, 128), p3 = b.new_buf(2, 128);
+    int X = b.new_buf(3, 512), Y = b.new_buf(3, 512);
+    int S0 = b.new_buf(3, C), S1 = b.new_buf(3, C), S2 = b.new_buf(3, C);
+    int catc = round_up(C + NH + NP, 32);
+    int CAT = b.new_buf(3, catc);
+    g.cat_buf = CAT; g.cat_channels = catc;
+
+    b.add(L_STEM, "model.0", "model.0.0", "model.0.1", false, 3, 32, 3, 2, 1, ACT_RELU, Builder::ref(-1, 3), Builder::ref(s1, 32));
+    // backbone blocks 1..11: dw then pw
+    int src = s1, src_ld = 32;
+    int dwbuf[11] = {d1, d2, d3, X, X, X, X, X, X, X, X};
+    int pwbuf[11] = {p1, p2, p3, Y, Y, Y, Y, Y, Y, Y, Y};
+    for (int i = 0; i < 11; ++i) {
+        int cin = kBackbone[i][0], cout = kBackbone[i][1], st = kBackbone[i][2], dl = kBackbone[i][3];
+        // blocks 4.. alternate X (dw out) / Y (pw out); block 4's dw reads p3 (level 2)
+        b.add(L_DW, fmt("model.%d.dw", i + 1), fmt("model.%d.0", i + 1), fmt("model.%d.1", i + 1), false, cin, cin, 3, st, dl,
+              ACT_RELU, Builder::ref(src, src_ld), Builder::ref(dwbuf[i], cin));
+        b.add(L_GEMM, fmt("model.%d.pw", i + 1), fmt("model.%d.3", i + 1), fmt("model.%d.4", i + 1), false, cin, cout, 1, 1, 1,
+              ACT_RELU, Builder::ref(dwbuf[i], cin), Builder::ref(pwbuf[i], cout));
+        src = pwbuf[i]; src_ld = cout;
+    }
+    // Cpm (with_mobilenet.py:18-21): a = align(x); feat = conv(a + trunk(a))
+    b.add(L_GEMM, "cpm.align", "cpm.align.0", "", true, 512, C, 1, 1, 1, ACT_RELU, Builder::ref(Y, 512), Builder::ref(S0, C));
+    int tin = S0;
+    for (int j = 0; j < 3; ++j) {
+        b.add(L_DW, fmt("cpm.trunk.%d.dw", j), fmt("cpm.trunk.%d.0", j), "", false, C, C, 3, 1, 1, ACT_ELU,
+              Builder::ref(tin, C), Builder::ref(S1, C));
+        Layer& pw = b.add(L_GEMM, fmt("cpm.trunk.%d.pw", j), fmt("cpm.trunk.%d.2", j), "", false, C, C, 1, 1, 1, ACT_ELU,
+                          Builder::ref(S1, C), Builder::ref(S2, C));
+        if (j == 2) pw.res = Builder::ref(S0, C);   // x + trunk(x), fused into the last pw's epilogue
+        tin = S2;
+    }
+    b.add(L_GEMM, "cpm.conv", "cpm.conv.0", "", true, C, C, 3, 1, 1, ACT_RELU, Builder::ref(S2, C), Builder::ref(CAT, catc, 0));
+    // initial stage (with_mobilenet.py:41-45)
+    b.add(L_GEMM, "initial_stage.trunk.0", "initial_stage.trunk.0.0", "", true, C, C, 3, 1, 1, ACT_RELU, Builder::ref(CAT, catc, 0), Builder::ref(S0, C));
+    b.add(L_GEMM, "initial_stage.trunk.1", "initial_stage.trunk.1.0", "", true, C, C, 3, 1, 1, ACT_RELU, Builder::ref(S0, C), Builder::ref(S1, C));
+    b.add(L_GEMM, "initial_stage.trunk.2", "initial_stage.trunk.2.0", "", true, C, C, 3, 1, 1, ACT_RELU, Builder::ref(S1, C), Builder::ref(S0, C));
+    b.add(L_GEMM, "initial_stage.heatmaps.0", "initial_stage.heatmaps.0.0", "", true, C, 512, 1, 1, 1, ACT_RELU, Builder::ref(S0, C), Builder::ref(X, 512));
+    b.add(L_GEMM, "initial_stage.pafs.0", "initial_stage.pafs.0.0", "", true, C, 512, 1, 1, 1, ACT_RELU, Builder::ref(S0, C), Builder::ref(Y, 512));
+    b.add(L_GEMM, "initial_stage.heatmaps.1", "initial_stage.heatmaps.1.0", "", true, 512, NH, 1, 1, 1, ACT_NONE, Builder::ref(X, 512), Builder::ref(CAT, catc, C)).out_index = 0;
+    b.add(L_GEMM, "initial_stage.pafs.1", "initial_stage.pafs.1.0", "", true, 512, NP, 1, 1, 1, ACT_NONE, Builder::ref(Y, 512), Builder::ref(CAT, catc, C + NH)).out_index = 1;
+    // refinement stages (with_mobilenet.py:57-60, 82-86)
+    for (int k = 0; k < nref; ++k) {
+        BufRef in = Builder::ref(CAT, catc, 0);
+        int in_c = C + NH + NP;
+        for (int bl = 0; bl < 5; ++bl) {
+            std::string q = fmt("refinement_stages.%d.trunk.%d", k, bl);
+            b.add(L_GEMM, q + ".initial", q + ".initial.0", "", true, in_c, C, 1, 1, 1, ACT_RELU, in, Builder::ref(S0, C));
+            b.add(L_GEMM, q + ".trunk.0", q + ".trunk.0.0", q + ".trunk.0.1", true, C, C, 3, 1, 1, ACT_RELU, Builder::ref(S0, C), Builder::ref(S1, C));
+            Layer& c2 = b.add(L_GEMM, q + ".trunk.1", q + ".trunk.1.0", q + ".trunk.1.1", true, C, C, 3, 1, 2, ACT_RELU,
+                              Builder::ref(S1, C), Builder::ref(S2, C));
+            c2.res = Builder::ref(S0, C);           // initial_features + trunk_features
+            in = Builder::ref(S2, C);
+            in_c = C;
+        }
+        std::string p = fmt("refinement_stages.%d", k);
+        b.add(L_GEMM, p + ".heatmaps.0", p + ".heatmaps.0.0", "", true, C, C, 1, 1, 1, ACT_RELU, Builder::ref(S2, C), Builder::ref(S0, C));
+        b.add(L_GEMM, p + ".pafs.0", p + ".pafs.0.0", "", true, C, C, 1, 1, 1, ACT_RELU, Builder::ref(S2, C), Builder::ref(S1, C));
+        b.add(L_GEMM, p + ".heatmaps.1", p + ".heatmaps.1.0", "", true, C, NH, 1, 1, 1, ACT_NONE, Builder::ref(S0, C), Builder::ref(CAT, catc, C)).out_index = 2 * (k + 1);
+        b.add(L_GEMM, p + ".pafs.1", p + ".pafs.1.0", "", true, C, NP, 1, 1, 1, ACT_NONE, Builder::ref(S1, C), Builder::ref(CAT, catc, C + NH)).out_index = 2 * (k + 1) + 1;
+    }
+    // weight blob layout
+    size_t off = 0;
+    for (Layer& l : g.layers) {
+        if (l.kind == L_STEM) {
+            l.cin_pad = 3; l.cout_pad = 32;
+            l.w_off = off; off += 27 * 32;
+        } else if (l.kind == L_DW) {
+            l.cin_pad = l.cin; l.cout_pad = l.cout;
+            l.w_off = off; off += (size_t)9 * l.cin;
+        } else {
+            l.cin_pad = round_up(l.cin, 32);
+            l.cout_pad = round_up(l.cout, 64);
+            l.w_off = off; off += (size_t)l.ks * l.ks * l.cout_pad * l.cin_pad;
+        }
+        l.b_off = off; off += l.cout_pad;
+        off = (off + 63) / 64 * 64;
+    }
+    g.blob_floats = off;
+    return g;
+}
+
+std::string pack_weights(const Graph& g, const std::vector<std::string>& names, const std::vector<HostTensor>& tensors,
+                         std::vector<float>& blob) {
+    std::map<std::string, const HostTensor*> by_name;
+    for (size_t i = 0; i < names.size(); ++i) by_name[names[i]] = &tensors[i];
+    // every key of the table must be there with the right shape (the Python load_state has already
+    // substituted the net's own values for missing / mismatching checkpoint entries)
+    for (const ParamSpec& p : param_table(g.nref, g.C, g.NH, g.NP)) {
+        auto it = by_name.find(p.key);
+        if (it == by_name.end()) return "missing parameter '" + p.key + "'";
+        if (p.role == LWP_ROLE_BN_NBT) continue;
+        const HostTensor& t = *it->second;
+        if (t.ndim != p.ndim) return "rank mismatch for '" + p.key + "'";
+        for (int d = 0; d < p.ndim; ++d)
+            if (t.shape[d] != p.shape[d]) return "shape mismatch for '" + p.key + "'";
+        if (!t.ptr) return "null data for '" + p.key + "'";
+    }
+    auto f32 = [&](const std::string& k) { return (const float*)by_name[k]->ptr; };
+    blob.assign(g.blob_floats, 0.0f);
+    for (const Layer& l : g.layers) {
+        const int co = l.cout;
+        std::vector<double> scale(co, 1.0), shift(co, 0.0);   // y = conv*scale + shift
+        const float* cb = l.has_bias ? f32(l.conv_key + ".bias") : nullptr;
+        if (!l.bn_key.empty()) {
+            const float* gam = f32(l.bn_key + ".weight");
+            const float* bet = f32(l.bn_key + ".bias");
+            const float* mu = f32(l.bn_key + ".running_mean");
+            const float* var = f32(l.bn_key + ".running_var");
+            for (int o = 0; o < co; ++o) {
+                scale[o] = (double)gam[o] / std::sqrt((double)var[o] + 1e-5);
+                shift[o] = ((cb ? (double)cb[o] : 0.0) - (double)mu[o]) * scale[o] + (double)bet[o];
+            }
+        } else if (cb) {
+            for (int o = 0; o < co; ++o) shift[o] = cb[o];
+        }
+        const float* w = f32(l.conv_key + ".weight");
+        float* wp = blob.data() + l.w_off;
+        float* bp = blob.data() + l.b_off;
+        for (int o = 0; o < co; ++o) bp[o] = (float)shift[o];
+        if (l.kind == L_STEM) {                 // OIHW (32,3,3,3) -> [(ky,kx,ci)][oc]
+            for (int o = 0; o < 32; ++o)
+                for (int ci = 0; ci < 3; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        wp[(t * 3 + ci) * 32 + o] = (float)((double)w[(o * 3 + ci) * 9 + t] * scale[o]);
+        } else if (l.kind == L_DW) {            // (C,1,3,3) -> [tap][C]
+            for (int c = 0; c < co; ++c)
+                for (int t = 0; t < 9; ++t) wp[(size_t)t * co + c] = (float)((double)w[c * 9 + t] * scale[c]);
+        } else {                                // OIHW -> [tap][cout_pad][cin_pad]
+            const int taps = l.ks * l.ks;
+            for (int o = 0; o < co; ++o)
+                for (int ci = 0; ci < l.cin; ++ci)
+                    for (int t = 0; t < taps; ++t)
+                        wp[((size_t)t * l.cout_pad + o) * l.cin_pad + ci] =
+                            (float)((double)w[((size_t)o * l.cin + ci) * taps + t] * scale[o]);
+        }
+    }
+    return "";
+}
+
+}  // namespace lwp

@@ -1,0 +1,307 @@
+// Network kernels for gfx950 (CDNA4), fp32 path.  Activations are NHWC float32.
+//
+//   stem_kernel   3x3 stride-2 conv 3->32 (+folded BN, ReLU), reads the NCHW input planes directly.
+//   dw_kernel     depthwise 3x3, stride 1/2, dilation 1/2, (+folded BN) ReLU | ELU.  HBM-bound:
+//                 16-byte channel vectors per lane, consecutive lanes on consecutive channels, so
+//                 every wave instruction moves whole 1-KiB rows.
+//   gemm_kernel   1x1 and dense 3x3 convs as an implicit GEMM on the f32-input matrix cores
+//                 (v_mfma_f32_32x32x2_f32: exact f32 fmaf chains, 157 TFLOP/s peak).  Tiles are
+//                 register-staged into padded LDS rows (36 floats: conflict-free ds_read_b128),
+//                 double-buffered, one barrier per 32-deep K step.
+#include "lwp_internal.h"
+
+namespace lwp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == ACT_ELU) return v > 0.0f ? v : expm1f(v);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------- stem
+// one thread = one output pixel x 4 output channels (8 threads per pixel -> 128-B row stores)
+__global__ void __launch_bounds__(256) stem_kernel(StemParams p) {
+    const int64_t total = (int64_t)p.N * p.Ho * p.Wo * 8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int og = (int)(idx & 7);
+    int64_t pix = idx >> 3;
+    const int xo = (int)(pix % p.Wo);
+    pix /= p.Wo;
+    const int yo = (int)(pix % p.Ho);
+    const int n = (int)(pix / p.Ho);
+    const float* in = p.in + (int64_t)n * 3 * p.H * p.W;
+    f32x4 acc = *(const f32x4*)(p.bias + og * 4);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yi = yo * 2 - 1 + ky;
+        if (yi < 0 || yi >= p.H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xi = xo * 2 - 1 + kx;
+            if (xi < 0 || xi >= p.W) continue;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float v = in[((int64_t)ci * p.H + yi) * p.W + xi];
+                const f32x4 w = *(const f32x4*)(p.w + ((ky * 3 + kx) * 3 + ci) * 32 + og * 4);
+                acc += v * w;
+            }
+        }
+    }
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    *(f32x4*)(p.out + (((int64_t)n * p.Ho + yo) * p.Wo + xo) * 32 + og * 4) = acc;
+}
+
+hipError_t launch_stem(const StemParams& p, hipStream_t s) {
+    const int64_t total = (int64_t)p.N * p.Ho * p.Wo * 8;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(stem_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------- depthwise
+// one thread = PX consecutive output pixels (along x) x 4 channels; the 3 x (PX*stride + 2*dil) input
+// columns are loaded once and reused across the PX outputs (stride 1) — fewer L1/L2 reads per output.
+template <int PX>
+__global__ void __launch_bounds__(256) dw_kernel(DwParams p) {
+    const int cg = p.C >> 2;
+    const int wgroups = (p.Wo + PX - 1) / PX;
+    const int64_t total = (int64_t)p.N * p.Ho * wgroups * cg;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % cg);
+    int64_t r = idx / cg;
+    const int xg = (int)(r % wgroups);
+    r /= wgroups;
+    const int yo = (int)(r % p.Ho);
+    const int n = (int)(r / p.Ho);
+    const int c = c4 * 4;
+    f32x4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = *(const f32x4*)(p.w + t * p.C + c);
+    const f32x4 b = *(const f32x4*)(p.bias + c);
+    f32x4 acc[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) acc[i] = b;
+    const float* in = p.in + (int64_t)n * p.Hi * p.Wi * p.in_ld + c;
+    const int x0 = xg * PX;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yi = yo * p.stride + (ky - 1) * p.dil;
+        if (yi < 0 || yi >= p.Hi) continue;
+        const float* row = in + (int64_t)yi * p.Wi * p.in_ld;
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xi = (x0 + i) * p.stride + (kx - 1) * p.dil;
+                if (xi < 0 || xi >= p.Wi) continue;
+                const f32x4 v = *(const f32x4*)(row + (int64_t)xi * p.in_ld);
+                acc[i] += v * w[ky * 3 + kx];
+            }
+        }
+    }
+    float* out = p.out + (((int64_t)n * p.Ho + yo) * p.Wo) * p.out_ld + c;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int xo = x0 + i;
+        if (xo >= p.Wo) break;
+        f32x4 v = acc[i];
+        v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act); v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+        *(f32x4*)(out + (int64_t)xo * p.out_ld) = v;
+    }
+}
+
+hipError_t launch_dw(const DwParams& p, hipStream_t s) {
+    const int cg = p.C >> 2;
+    // few pixels per thread when the map is small (keep the chip full), more when it is large
+    const int64_t pixels = (int64_t)p.N * p.Ho * p.Wo;
+    if (pixels * cg >= (int64_t)256 * 256 * 16) {
+        const int64_t total = (int64_t)p.N * p.Ho * ((p.Wo + 1) / 2) * cg;
+        hipLaunchKernelGGL(dw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    } else {
+        const int64_t total = pixels * cg;
+        hipLaunchKernelGGL(dw_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------- implicit GEMM
+// out[m][n] = act(sum_{tap,c} in[pix(m)+off(tap)][c] * w[tap][n][c] + bias[n]) (+ res[m][n])
+//   m: output pixel (N*H*W, stride-1 convs only), n: output channel, K = taps * cin_pad.
+// Workgroup tile BM x BN, WM x WN waves, each wave a 32x32 accumulator (v_mfma_f32_32x32x2_f32).
+// K is walked in steps of 32 channels inside one tap.  LDS rows are [row][32 + 4 pad] floats: a lane
+// (row r = lane&31, half h = lane>>5) reads 4 consecutive k with one ds_read_b128 at k = 8s + 4h; MFMA
+// (s,t) then contracts k in {8s+t, 8s+4+t} on the A and the B side alike (any k order is a valid GEMM).
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+template <int BM, int BN>
+__global__ void __launch_bounds__((BM / 32) * (BN / 32) * 64) gemm_kernel(GemmParams p) {
+    constexpr int WM = BM / 32, WN = BN / 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int A_CHUNKS = BM * (BK / 4);         // 16-byte chunks per A tile
+    constexpr int B_CHUNKS = BN * (BK / 4);
+    constexpr int A_PER = (A_CHUNKS + NT - 1) / NT;
+    constexpr int B_PER = (B_CHUNKS + NT - 1) / NT;
+    static_assert(A_CHUNKS % NT == 0 && B_CHUNKS % NT == 0, "tile/threads mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                               // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;             // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    const int ntn = p.cout_pad / BN;
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+    // run of logical tiles so the BN-neighbours that re-read one A tile hit the same L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / ntn, tile_n = bid % ntn;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // per-thread staging assignment: chunk id -> (row, 16-B column)
+    int a_row[A_PER], a_col[A_PER], a_y[A_PER], a_x[A_PER];
+    int64_t a_base[A_PER];
+    bool a_ok[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int ch = tid + i * NT;
+        a_row[i] = ch / (BK / 4);
+        a_col[i] = (ch % (BK / 4)) * 4;
+        const int64_t m = m0 + a_row[i];
+        a_ok[i] = m < M;
+        const int64_t mm = a_ok[i] ? m : 0;
+        a_x[i] = (int)(mm % p.W);
+        a_y[i] = (int)((mm / p.W) % p.H);
+        a_base[i] = mm * p.in_ld;
+    }
+    int b_row[B_PER], b_col[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int ch = tid + i * NT;
+        b_row[i] = ch / (BK / 4);
+        b_col[i] = (ch % (BK / 4)) * 4;
+    }
+
+    const int ksteps_per_tap = p.cin_pad / BK;
+    const int taps = p.ks * p.ks;
+    const int nsteps = taps * ksteps_per_tap;
+
+    f32x4 a_reg[A_PER], b_reg[B_PER];
+    auto load_step = [&](int step) {
+        const int tap = step / ksteps_per_tap;
+        const int c0 = (step - tap * ksteps_per_tap) * BK;
+        int dy = 0, dx = 0;
+        if (p.ks == 3) { dy = (tap / 3 - 1) * p.dil; dx = (tap % 3 - 1) * p.dil; }
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+            const bool ok = a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *(const f32x4*)(p.in + a_base[i] + ((int64_t)dy * p.W + dx) * p.in_ld + c0 + a_col[i]);
+            a_reg[i] = v;
+        }
+        const float* wt = p.w + ((int64_t)tap * p.cout_pad + n0) * p.cin_pad + c0;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) b_reg[i] = *(const f32x4*)(wt + (int64_t)b_row[i] * p.cin_pad + b_col[i]);
+    };
+    auto store_step = [&](int buf) {
+        float* a = As + buf * BM * LDS_LD;
+        float* b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) *(f32x4*)(a + a_row[i] * LDS_LD + a_col[i]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) *(f32x4*)(b + b_row[i] * LDS_LD + b_col[i]) = b_reg[i];
+    };
+
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) load_step(step + 1);
+        const float* a = As + buf * BM * LDS_LD + (wm * 32 + r) * LDS_LD + 4 * h;
+        const float* b = Bs + buf * BN * LDS_LD + (wn * 32 + r) * LDS_LD + 4 * h;
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            const f32x4 av = *(const f32x4*)(a + 8 * s);
+            const f32x4 bv = *(const f32x4*)(b + 8 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        }
+        if (step + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds column n = n0 + wn*32 + r, rows (i&3) + 8*(i>>2) + 4*h of the wave tile
+    const int n = n0 + wn * 32 + r;
+    if (n < p.cout) {
+        const float bias = p.bias[n];
+        const int64_t HW = (int64_t)p.H * p.W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t m = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (m < M) {
+                float v = apply_act(acc[i] + bias, p.act);
+                if (p.res) v += p.res[m * p.res_ld + n];
+                p.out[m * p.out_ld + n] = v;
+                if (p.out_nchw) {
+                    const int64_t img = m / HW, pix = m - img * HW;
+                    p.out_nchw[(img * p.cout + n) * HW + pix] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static hipError_t launch_gemm_t(const GemmParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    const int64_t tiles = ((M + BM - 1) / BM) * (p.cout_pad / BN);
+    constexpr int NT = (BM / 32) * (BN / 32) * 64;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN>), dim3((unsigned)tiles), dim3(NT), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    const int64_t t64 = ((M + 63) / 64) * (p.cout_pad / 64);
+    // small problems: 32-row tiles double the workgroup count so more of the 256 CUs have work
+    if (t64 < 512) return launch_gemm_t<32, 64>(p, s);
+    return launch_gemm_t<64, 64>(p, s);
+}
+
+// ---------------------------------------------------------------------------------------- layout helper
+__global__ void __launch_bounds__(256) nchw_from_nhwc_kernel(const float* src, int src_ld, float* dst, int N, int HW, int C) {
+    const int64_t total = (int64_t)N * C * HW;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int pix = (int)(idx % HW);
+    const int64_t t = idx / HW;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    dst[idx] = src[((int64_t)n * HW + pix) * src_ld + c];
+}
+hipError_t launch_nchw_from_nhwc(const float* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s) {
+    const int64_t total = (int64_t)N * C * HW;
+    hipLaunchKernelGGL(nchw_from_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, src_ld, dst, N, HW, C);
+    return hipGetLastError();
+}
+
+}  // namespace lwp

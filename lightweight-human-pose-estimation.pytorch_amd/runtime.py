@@ -1,0 +1,245 @@
+"""Host-side engine over one C-ABI handle: marshals numpy / torch buffers to the library.
+
+PyTorch is used only as a tensor container (device memory, ``data_ptr()``); every computation
+is a HIP kernel behind include/lwpose.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MEM_DEVICE, MEM_HOST, check, lib
+
+_ROLE_NBT = 6
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Engine(object):
+    def __init__(self, device_id=0, nref=1, num_channels=128, num_heatmaps=19, num_pafs=38, dtype=_lib.F32):
+        self.h = _lib.Handle(device_id, nref, num_channels, num_heatmaps, num_pafs, dtype)
+        self.nref, self.C, self.NH, self.NP = nref, num_channels, num_heatmaps, num_pafs
+        self.device_id = device_id
+        self._keep = None
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state_dict):
+        """state_dict: key -> torch tensor / numpy array (float32; num_batches_tracked int64)."""
+        names, arrs = [], []
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            if a.dtype != np.int64:
+                a = np.ascontiguousarray(a, dtype=np.float32)
+            names.append(k.encode())
+            arrs.append(np.ascontiguousarray(a))
+        n = len(names)
+        c_names = (C.c_char_p * n)(*names)
+        c_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        shapes = np.ones((n, 4), dtype=np.int64)
+        ndims = np.zeros(n, dtype=np.int32)
+        for i, a in enumerate(arrs):
+            ndims[i] = a.ndim
+            shapes[i, :a.ndim] = a.shape
+        check(lib().lwp_load_weights(self.h.ptr, c_names, c_ptrs, shapes.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     ndims.ctypes.data_as(C.POINTER(C.c_int)), n), self.h.ptr)
+
+    def weights_blob_bytes(self):
+        n = C.c_size_t()
+        check(lib().lwp_weights_blob_bytes(self.h.ptr, C.byref(n)), self.h.ptr)
+        return n.value
+
+    def export_weights(self, device_tensor):
+        check(lib().lwp_weights_blob_export(self.h.ptr, device_tensor.data_ptr(), device_tensor.numel() * device_tensor.element_size()), self.h.ptr)
+
+    def import_weights(self, device_tensor):
+        check(lib().lwp_weights_blob_import(self.h.ptr, device_tensor.data_ptr(), device_tensor.numel() * device_tensor.element_size()), self.h.ptr)
+
+    def set_capacity(self, max_peaks=2048, max_kpts=128, max_conn=4096, max_entries=256):
+        check(lib().lwp_set_capacity(self.h.ptr, max_peaks, max_kpts, max_conn, max_entries), self.h.ptr)
+        self._caps = (max_peaks, max_kpts, max_conn, max_entries)
+
+    @property
+    def caps(self):
+        return getattr(self, "_caps", (2048, 128, 4096, 256))
+
+    # ------------------------------------------------------------------ network
+    def forward(self, x):
+        """x: (N,3,H,W) float32 torch tensor (cpu or cuda) or numpy array -> list of 2(1+nref) outputs of the
+        same kind (NCHW), like PoseEstimationWithMobileNet.forward (with_mobilenet.py:114-123)."""
+        torch = _torch()
+        is_np = isinstance(x, np.ndarray)
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if is_np else x
+        if t.dim() != 4 or t.shape[1] != 3:
+            raise ValueError("expected input of shape (N, 3, H, W), got %s" % (tuple(t.shape),))
+        t = t.detach().to(torch.float32).contiguous()
+        N, _, H, W = t.shape
+        on_dev = t.is_cuda
+        if on_dev and t.device.index != self.device_id:
+            raise ValueError("input is on cuda:%d but the engine lives on cuda:%d" % (t.device.index, self.device_id))
+        shapes = [(N, self.NP if i % 2 else self.NH, H // 8, W // 8) for i in range(2 * (1 + self.nref))]
+        outs = [torch.empty(s, dtype=torch.float32, device=t.device) for s in shapes]
+        ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        if on_dev:
+            torch.cuda.current_stream(t.device).synchronize()
+        mem = MEM_DEVICE if on_dev else MEM_HOST
+        check(lib().lwp_forward(self.h.ptr, t.data_ptr(), mem, N, H, W, ptrs, mem), self.h.ptr)
+        if on_dev:
+            self.synchronize()
+        return [o.numpy() for o in outs] if is_np else outs
+
+    def synchronize(self):
+        check(lib().lwp_synchronize(self.h.ptr), self.h.ptr)
+
+    # ------------------------------------------------------------------ post-processing pieces
+    def upsample(self, maps_nchw, ratio=4):
+        """(N,C,h,w) float32 numpy -> (N, h*r, w*r, C) float32 numpy (cv2.resize INTER_CUBIC, demo.py:72,76)."""
+        if getattr(maps_nchw, "is_cuda", False):
+            a = maps_nchw.detach().contiguous()
+            _torch().cuda.current_stream(a.device).synchronize()
+            ptr, mem = a.data_ptr(), MEM_DEVICE
+        else:
+            a = np.ascontiguousarray(maps_nchw.numpy() if hasattr(maps_nchw, "numpy") else maps_nchw, dtype=np.float32)
+            ptr, mem = a.ctypes.data, MEM_HOST
+        N, Cc, h, w = a.shape
+        out = np.empty((N, h * ratio, w * ratio, Cc), dtype=np.float32)
+        check(lib().lwp_upsample(self.h.ptr, ptr, mem, N, Cc, h, w, ratio, out.ctypes.data, MEM_HOST), self.h.ptr)
+        return out
+
+    def extract_keypoints(self, heatmap):
+        """In-place threshold of ``heatmap`` (2-D float32 view) and key-point list [(x, y, score)]."""
+        if not isinstance(heatmap, np.ndarray) or heatmap.ndim != 2 or heatmap.dtype != np.float32:
+            raise TypeError("heatmap must be a 2-D float32 numpy array (view)")
+        if not heatmap.flags.writeable:
+            raise ValueError("heatmap must be writeable (it is thresholded in place)")
+        H, W = heatmap.shape
+        if heatmap.strides[0] % 4 or heatmap.strides[1] % 4:
+            raise ValueError("unsupported strides")
+        cap = self.caps[1]
+        xs = np.empty(cap, np.int64); ys = np.empty(cap, np.int64); sc = np.empty(cap, np.float32)
+        n = C.c_int()
+        check(lib().lwp_extract_keypoints(self.h.ptr, heatmap.ctypes.data, H, W, heatmap.strides[0] // 4, heatmap.strides[1] // 4,
+                                          xs.ctypes.data_as(C.POINTER(C.c_int64)), ys.ctypes.data_as(C.POINTER(C.c_int64)),
+                                          sc.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)), self.h.ptr)
+        return xs[:n.value], ys[:n.value], sc[:n.value]
+
+    def group_keypoints(self, kpts, type_counts, pafs, demo):
+        """kpts (K,4) float64, type_counts (18,), pafs (H,W,38) float32 -> (P,20) float64."""
+        pafs = np.ascontiguousarray(pafs, dtype=np.float32)
+        H, W, NPc = pafs.shape
+        if NPc != self.NP:
+            raise ValueError("pafs must have %d channels" % self.NP)
+        kp = np.ascontiguousarray(kpts, dtype=np.float64).reshape(-1, 4)
+        tc = np.ascontiguousarray(type_counts, dtype=np.int32)
+        cap = self.caps[3]
+        ent = np.empty((cap, 20), np.float64)
+        n = C.c_int()
+        check(lib().lwp_group_keypoints(self.h.ptr, kp.ctypes.data, tc.ctypes.data_as(C.POINTER(C.c_int)), pafs.ctypes.data,
+                                        MEM_HOST, H, W, 1 if demo else 0, ent.ctypes.data, cap, C.byref(n)), self.h.ptr)
+        return ent[:n.value].copy()
+
+    # ------------------------------------------------------------------ fused pipeline
+    def _result_buffers(self, N):
+        kcap = 18 * self.caps[1]
+        ecap = self.caps[3]
+        return (np.zeros((N, 18), np.int32), np.zeros((N, kcap, 4), np.float64), np.zeros((N, ecap, 20), np.float64),
+                np.zeros(N, np.int32), kcap, ecap)
+
+    @staticmethod
+    def _unpack(N, counts, kpts, ent, ne):
+        out = []
+        for f in range(N):
+            K = int(counts[f].sum())
+            out.append((ent[f, :ne[f]].copy(), kpts[f, :K].copy(), counts[f].copy()))
+        return out
+
+    def infer_poses(self, x, upsample_ratio=4, demo=True):
+        """x: (N,3,H,W) float32 (numpy / cpu tensor / cuda tensor), already normalised and padded.
+        Returns per frame (pose_entries (P,20) f64, all_keypoints (K,4) f64, type_counts (18,))."""
+        torch = _torch()
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if isinstance(x, np.ndarray) else x
+        t = t.detach().to(torch.float32).contiguous()
+        N, _, H, W = t.shape
+        counts, kpts, ent, ne, kcap, ecap = self._result_buffers(N)
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        check(lib().lwp_infer_poses(self.h.ptr, t.data_ptr(), MEM_DEVICE if t.is_cuda else MEM_HOST, N, H, W, upsample_ratio,
+                                    1 if demo else 0, counts.ctypes.data_as(C.POINTER(C.c_int)), kpts.ctypes.data, kcap,
+                                    ent.ctypes.data, ecap, ne.ctypes.data_as(C.POINTER(C.c_int))), self.h.ptr)
+        return self._unpack(N, counts, kpts, ent, ne)
+
+    def poses_from_maps(self, heat_nchw, paf_nchw, upsample_ratio=4, demo=True):
+        """Post-processing only, from low-res stage outputs (N,19,h,w) / (N,38,h,w) float32 numpy."""
+        heat = np.ascontiguousarray(heat_nchw, dtype=np.float32)
+        paf = np.ascontiguousarray(paf_nchw, dtype=np.float32)
+        N, _, hs, ws = heat.shape
+        counts, kpts, ent, ne, kcap, ecap = self._result_buffers(N)
+        check(lib().lwp_poses_from_maps(self.h.ptr, heat.ctypes.data, paf.ctypes.data, MEM_HOST, N, hs, ws, upsample_ratio,
+                                        1 if demo else 0, counts.ctypes.data_as(C.POINTER(C.c_int)), kpts.ctypes.data, kcap,
+                                        ent.ctypes.data, ecap, ne.ctypes.data_as(C.POINTER(C.c_int))), self.h.ptr)
+        return self._unpack(N, counts, kpts, ent, ne)
+
+    def layers(self):
+        out = []
+        name = C.create_string_buffer(128)
+        v = [C.c_int() for _ in range(6)]
+        for i in range(lib().lwp_layer_count(self.h.ptr)):
+            check(lib().lwp_layer_info(self.h.ptr, i, name, 128, *[C.byref(x) for x in v]), self.h.ptr)
+            out.append(dict(index=i, name=name.value.decode(), kind=v[0].value, cin=v[1].value, cout=v[2].value,
+                            ksize=v[3].value, stride=v[4].value, dilation=v[5].value))
+        return out
+
+    def debug_layer_output(self, x, layer_index):
+        """Output of layer ``layer_index`` (NCHW float32 numpy) for input x (N,3,H,W) numpy."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        N, _, H, W = x.shape
+        info = self.layers()[layer_index]
+        buf = np.empty(N * info["cout"] * ((H + 1) // 2) * ((W + 1) // 2), np.float32)
+        dims = (C.c_int * 4)()
+        check(lib().lwp_debug_layer_output(self.h.ptr, x.ctypes.data, N, H, W, layer_index, buf.ctypes.data, buf.size, dims), self.h.ptr)
+        n = dims[0] * dims[1] * dims[2] * dims[3]
+        return buf[:n].reshape(dims[0], dims[1], dims[2], dims[3]).copy()
+
+    def infer_poses_async(self, x_cuda, upsample_ratio=4, demo=True):
+        N, _, H, W = x_cuda.shape
+        self._keep = x_cuda
+        check(lib().lwp_infer_poses_async(self.h.ptr, x_cuda.data_ptr(), N, H, W, upsample_ratio, 1 if demo else 0), self.h.ptr)
+        self._last_N = N
+
+    def fetch_poses(self):
+        N = self._last_N
+        counts, kpts, ent, ne, kcap, ecap = self._result_buffers(N)
+        check(lib().lwp_fetch_poses(self.h.ptr, counts.ctypes.data_as(C.POINTER(C.c_int)), kpts.ctypes.data, kcap, ent.ctypes.data,
+                                    ecap, ne.ctypes.data_as(C.POINTER(C.c_int))), self.h.ptr)
+        return self._unpack(N, counts, kpts, ent, ne)
+
+    # ------------------------------------------------------------------ measurement
+    def time_pipeline(self, x_cuda, iters, what=1, upsample_ratio=4, demo=True):
+        """milliseconds for ``iters`` back-to-back passes (HIP events on the engine's stream)."""
+        N, _, H, W = x_cuda.shape
+        ms = C.c_float()
+        check(lib().lwp_time_pipeline(self.h.ptr, x_cuda.data_ptr(), N, H, W, upsample_ratio, 1 if demo else 0, what, iters, C.byref(ms)), self.h.ptr)
+        self._last_N = N
+        return ms.value
+
+    def profile_classes(self, x_cuda, reps=5, upsample_ratio=4, demo=True):
+        N, _, H, W = x_cuda.shape
+        ms = (C.c_float * 6)()
+        ln = (C.c_int * 6)()
+        check(lib().lwp_profile_classes(self.h.ptr, x_cuda.data_ptr(), N, H, W, upsample_ratio, 1 if demo else 0, reps, ms, ln), self.h.ptr)
+        names = ["stem", "depthwise", "pointwise_1x1", "dense_3x3", "post", "other"]
+        return {n: {"ms": ms[i], "launches": ln[i]} for i, n in enumerate(names)}
+
+
+_default = {}
+
+
+def default_engine(device_id=None):
+    """Shared engine for the free functions (extract_keypoints / group_keypoints / up-sampling)."""
+    if device_id is None:
+        device_id = 0
+    if device_id not in _default:
+        _default[device_id] = Engine(device_id)
+    return _default[device_id]

@@ -160,3 +160,45 @@ def make_pose_maps(n_people, h=46, w=82, seed=0, drop_prob=0.1, noise=0.01):
     heat = heat + noise * nz[:19]
     paf = paf + noise * nz[19:]
     return heat.astype(np.float32), paf.astype(np.float32), people
+
+
+def calibrate_heads(sd, heat_raw, paf_raw, num_refinement_stages=1, peaks_per_channel=10, score_scale=0.25,
+                    paf_mean=0.3, paf_std=0.1):
+    """Affine re-parameterisation of the LAST stage's final 1x1 convs so that random-init maps look like a
+    trained net's to the post-processing: per heat-map channel about ``peaks_per_channel`` low-res pixels
+    exceed the 0.1 threshold (reference keypoints.py:17); every PAF channel gets mean ``paf_mean`` and std
+    ``paf_std`` so a realistic share of candidate limbs passes the line integral (keypoints.py:129-137).
+
+    heat_raw (NH,h,w) / paf_raw (NP,h,w): final-stage outputs obtained with ``sd`` on a sample frame (from any
+    forward provider).  Returns a new state dict; only 4 tensors change."""
+    import torch
+    p = "refinement_stages.%d" % (num_refinement_stages - 1) if num_refinement_stages > 0 else "initial_stage"
+    out = OrderedDict(sd)
+    heat_raw = np.asarray(heat_raw, dtype=np.float64)
+    paf_raw = np.asarray(paf_raw, dtype=np.float64)
+
+    def to_np(t):
+        return t.detach().cpu().numpy().astype(np.float64) if hasattr(t, "detach") else np.asarray(t, dtype=np.float64)
+
+    def put(key, arr, like):
+        arr = np.ascontiguousarray(arr.astype(np.float32))
+        out[key] = torch.from_numpy(arr) if hasattr(like, "detach") else arr
+
+    w, b = to_np(sd[p + ".heatmaps.1.0.weight"]), to_np(sd[p + ".heatmaps.1.0.bias"])
+    for c in range(heat_raw.shape[0]):
+        v = heat_raw[c].ravel()
+        q = np.quantile(v, max(0.0, 1.0 - peaks_per_channel / float(v.size)))
+        g = score_scale / max(v.std(), 1e-12)
+        w[c] *= g
+        b[c] = (b[c] - q) * g + 0.1
+    put(p + ".heatmaps.1.0.weight", w, sd[p + ".heatmaps.1.0.weight"])
+    put(p + ".heatmaps.1.0.bias", b, sd[p + ".heatmaps.1.0.bias"])
+    w, b = to_np(sd[p + ".pafs.1.0.weight"]), to_np(sd[p + ".pafs.1.0.bias"])
+    for c in range(paf_raw.shape[0]):
+        v = paf_raw[c].ravel()
+        g = paf_std / max(v.std(), 1e-12)
+        w[c] *= g
+        b[c] = (b[c] - v.mean()) * g + paf_mean
+    put(p + ".pafs.1.0.weight", w, sd[p + ".pafs.1.0.weight"])
+    put(p + ".pafs.1.0.bias", b, sd[p + ".pafs.1.0.bias"])
+    return out

@@ -1,0 +1,66 @@
+"""Host pre-processing helpers with the reference's names and semantics (reference: val.py:30-49).
+
+OpenCV is not a dependency: ``cv2.copyMakeBorder(BORDER_CONSTANT)`` is a constant fill + copy and the
+uint8 ``cv2.resize(INTER_CUBIC)`` is restated from OpenCV's fixed-point algorithm (11-bit coefficients,
+A = -0.75) — unpinned against cv2 itself, which is absent from the build container.
+"""
+import math
+
+import numpy as np
+
+
+def normalize(img, img_mean, img_scale):
+    # float32 image minus an integer tuple promotes to float64 under NumPy 2, exactly like the reference
+    return (np.array(img, dtype=np.float32) - img_mean) * img_scale
+
+
+def pad_width(img, stride, pad_value, min_dims):
+    """Centre-pad ``img`` to (min_dims rounded up to ``stride``); returns (padded, [top, left, bottom, right]).
+    Mutates ``min_dims`` like the reference (val.py:39-41)."""
+    h, w, _ = img.shape
+    h = min(min_dims[0], h)
+    min_dims[0] = math.ceil(min_dims[0] / float(stride)) * stride
+    min_dims[1] = math.ceil(max(min_dims[1], w) / float(stride)) * stride
+    top = int(math.floor((min_dims[0] - h) / 2.0))
+    left = int(math.floor((min_dims[1] - w) / 2.0))
+    pad = [top, left, int(min_dims[0] - h - top), int(min_dims[1] - w - left)]
+    out = np.empty((img.shape[0] + pad[0] + pad[2], w + pad[1] + pad[3], img.shape[2]), dtype=img.dtype)
+    out[...] = np.asarray(pad_value, dtype=img.dtype)[:img.shape[2]]
+    out[pad[0]:pad[0] + img.shape[0], pad[1]:pad[1] + w] = img
+    return out, pad
+
+
+def _cubic_coeffs_f32(x):
+    f = np.float32
+    x = f(x); A = f(-0.75)
+    c0 = ((A * (x + f(1)) - f(5) * A) * (x + f(1)) + f(8) * A) * (x + f(1)) - f(4) * A
+    c1 = ((A + f(2)) * x - (A + f(3))) * x * x + f(1)
+    c2 = ((A + f(2)) * (f(1) - x) - (A + f(3))) * (f(1) - x) * (f(1) - x) + f(1)
+    return np.array([c0, c1, c2, f(1) - c0 - c1 - c2], dtype=np.float32)
+
+
+def _axis_tables_u8(n_src, n_dst, inv_scale):
+    d = np.arange(n_dst)
+    f = ((d + 0.5) * (1.0 / inv_scale) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    frac = f - s.astype(np.float32)
+    idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+    w = np.stack([_cubic_coeffs_f32(t) for t in frac]) * np.float32(2048)
+    return idx, np.clip(np.rint(w), -32768, 32767).astype(np.int64)
+
+
+def resize_cubic_u8(img, fx, fy):
+    """cv2.resize(img, (0,0), fx=fx, fy=fy, interpolation=cv2.INTER_CUBIC) for uint8 HxWxC images (demo.py:59)."""
+    img = np.asarray(img)
+    if img.dtype != np.uint8:
+        raise TypeError("resize_cubic_u8 expects uint8")
+    h, w = img.shape[:2]
+    dw, dh = int(round(w * fx)), int(round(h * fy))
+    if (dw, dh) == (w, h) and fx == 1 and fy == 1:
+        return img.copy()
+    xi, xw = _axis_tables_u8(w, dw, fx)
+    yi, yw = _axis_tables_u8(h, dh, fy)
+    src = img.astype(np.int64)
+    t = sum(src[:, xi[:, k]] * xw[None, :, k, None] for k in range(4))
+    o = sum(t[yi[:, k]] * yw[:, k, None, None] for k in range(4))
+    return np.clip((o + (1 << 21)) >> 22, 0, 255).astype(np.uint8)

@@ -1,0 +1,298 @@
+"""GPU parity tests proper (-m gpu): every call goes through the C-ABI (liblwpose_hip.so) and is
+compared with the CPU oracle (oracle/, pinned to the reference by tests/golden) on the same inputs.
+
+Bars:  network fp32  : max-abs <= 1e-3 vs the oracle forward (north_star), measured ~1e-5;
+       post-processing: bit-exact (integer / float64 / exact float32 arithmetic)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lwpose_amd  # noqa: F401
+from lwpose_amd import synth
+from lwpose_amd.models.with_mobilenet import PoseEstimationWithMobileNet
+from lwpose_amd.modules import keypoints as kp_mod
+from lwpose_amd.modules.load_state import load_state
+from lwpose_amd.runtime import Engine
+from oracle import net_ref, post_ref
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+NET_TOL = 1e-3
+
+
+def net_input(n, h, w, seed):
+    fr = synth.make_frames(n, h, w, seed0=seed)
+    x = (fr.astype(np.float32) - 128.0) * np.float32(1 / 256)
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+
+
+_nets = {}
+
+
+def get_net(nref, seed, head_gain=1.0, heat_bias=0.0):
+    key = (nref, seed, head_gain, heat_bias)
+    if key not in _nets:
+        net = PoseEstimationWithMobileNet(num_refinement_stages=nref)
+        sd = synth.make_state_dict(nref, seed=seed, head_gain=head_gain, heat_bias=heat_bias)
+        load_state(net, {"state_dict": sd})
+        _nets[key] = (net.eval().cuda(), sd)
+    return _nets[key]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return Engine(0)
+
+
+def test_library_is_loaded_and_device_is_gfx950():
+    from lwpose_amd import _lib
+    assert _lib.lib().lwp_version() >= 100
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    maps = open("/proc/self/maps").read()
+    assert "liblwpose_hip.so" in maps
+
+
+# ------------------------------------------------------------------------------------------ network
+@pytest.mark.parametrize("nref", [1, 3])
+def test_per_layer_parity_small(nref):
+    """Every layer's output against the oracle's intermediate activations (2 x 3 x 64 x 96)."""
+    net, sd = get_net(nref, 1)
+    x = net_input(2, 64, 96, seed=100)
+    taps = {}
+    outs = net_ref.forward(sd, torch.from_numpy(x), nref, taps)
+    eng = net.engine
+    worst = []
+    name_map = {"cpm.conv": "cpm"}
+    for info in eng.layers():
+        nm = info["name"]
+        key = None
+        if nm.endswith(".dw") and nm.startswith("model."):
+            key = nm
+        elif nm.endswith(".pw") and nm.startswith("model."):
+            key = nm[:-3]
+        elif nm == "model.0" or nm == "cpm.align" or nm.startswith("initial_stage.trunk."):
+            key = nm
+        elif nm in name_map:
+            key = name_map[nm]
+        elif nm.startswith("refinement_stages.") and nm.endswith(".trunk.1"):
+            key = nm[:-len(".trunk.1")]
+        if key is None or key not in taps:
+            continue
+        got = eng.debug_layer_output(x, info["index"])
+        ref = taps[key].numpy()
+        assert got.shape == ref.shape, (nm, got.shape, ref.shape)
+        err = float(np.abs(got - ref).max())
+        scale = max(1.0, float(np.abs(ref).max()))
+        worst.append((err / scale, nm))
+        assert err <= NET_TOL * scale, "layer %s: max-abs err %g (scale %g)" % (nm, err, scale)
+    assert len(worst) >= 30
+    got = net(x)
+    for g, o in zip(got, outs):
+        assert np.abs(g - o.numpy()).max() <= NET_TOL
+
+
+def test_net_matches_reference_golden_small():
+    """Straight against the outputs captured from the reference itself."""
+    for nref in (1, 3):
+        g = np.load(os.path.join(GOLDEN, "net_small_nref%d.npz" % nref))
+        net, _ = get_net(nref, 1)
+        outs = net(net_input(2, 64, 96, seed=100))
+        assert len(outs) == 2 * (1 + nref)
+        for i, o in enumerate(outs):
+            assert np.abs(o - g["out%d" % i]).max() <= NET_TOL
+
+
+def test_net_mid_batch3_odd_maps_golden():
+    g = np.load(os.path.join(GOLDEN, "net_mid_nref1.npz"))
+    net, _ = get_net(1, 7)
+    outs = net(net_input(3, 184, 328, seed=200))
+    for i, o in enumerate(outs):
+        assert o.shape == g["out%d" % i].shape
+        assert np.abs(o - g["out%d" % i]).max() <= NET_TOL
+
+
+def test_net_full_368x656_golden_and_oracle():
+    g = np.load(os.path.join(GOLDEN, "net_full_nref1.npz"))
+    net, sd = get_net(1, 1, head_gain=4.0)
+    x = net_input(1, 368, 656, seed=0)
+    outs = net(x)
+    ref = net_ref.forward(sd, torch.from_numpy(x), 1)
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == tuple(g["out%d_shape" % i])
+        assert np.abs(o.reshape(-1)[::5] - g["out%d_sample" % i]).max() <= NET_TOL
+        assert np.abs(o - ref[i].numpy()).max() <= NET_TOL
+
+
+def test_net_cuda_tensor_in_out_and_batch_consistency():
+    net, _ = get_net(1, 1)
+    x = net_input(4, 128, 192, seed=300)
+    outs_np = net(x)
+    xt = torch.from_numpy(x).cuda()
+    outs_t = net(xt)
+    assert all(o.is_cuda for o in outs_t)
+    for a, b in zip(outs_np, outs_t):
+        assert np.array_equal(a, b.cpu().numpy())
+    single = net(x[2:3])
+    for a, b in zip(outs_np, single):
+        assert np.abs(a[2:3] - b).max() <= 1e-5     # frames are independent (data-parallel sharding relies on it)
+
+
+def test_load_state_semantics_match_reference_golden(capsys):
+    import json
+    ref = json.load(open(os.path.join(GOLDEN, "load_state.json")))
+    net = PoseEstimationWithMobileNet(1)
+    sd = synth.make_state_dict(1, seed=3)
+    del sd["model.3.0.weight"]
+    sd["cpm.align.0.bias"] = sd["cpm.align.0.bias"][:64].clone()
+    sd["not.a.key"] = torch.zeros(3)
+    before = net.state_dict()
+    load_state(net, {"state_dict": sd})
+    assert capsys.readouterr().out == ref["stdout"]
+    after = net.state_dict()
+    kept = [k for k in after if torch.equal(after[k], before[k]) and not (k in sd and tuple(sd[k].shape) == tuple(after[k].shape)
+                                                                          and torch.equal(after[k], sd[k]))]
+    assert kept == ref["kept"]
+
+
+def test_errors_are_loud(eng):
+    net = PoseEstimationWithMobileNet(1)
+    with pytest.raises(ValueError):
+        net.cuda()(np.zeros((1, 3, 60, 64), np.float32))        # H not a multiple of the stride
+    with pytest.raises(RuntimeError):
+        net.cpu()
+    with pytest.raises(TypeError):
+        eng.extract_keypoints(np.zeros((4, 4), np.float64))
+
+
+# ------------------------------------------------------------------------------------------ upsample
+@pytest.mark.parametrize("ratio", [4, 8])
+def test_upsample_bit_exact(eng, ratio):
+    heat, paf, _ = synth.make_pose_maps(3, 23, 41, 11)
+    for m in (heat, paf):
+        got = eng.upsample(m[None], ratio)[0]
+        ref = post_ref.upsample_cubic(m.transpose(1, 2, 0), ratio)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref)
+    b = np.stack([heat, heat[::-1].copy()])
+    got = eng.upsample(b, ratio)
+    assert np.array_equal(got[1], post_ref.upsample_cubic(b[1].transpose(1, 2, 0), ratio))
+
+
+# ------------------------------------------------------------------------------------------ extract
+def test_extract_adversarial_golden(eng):
+    g = np.load(os.path.join(GOLDEN, "extract_adversarial.npz"))
+    for nm in [k[3:] for k in g.files if k.startswith("in:")]:
+        hm = g["in:" + nm].copy()
+        lst = []
+        n = kp_mod.extract_keypoints(hm, lst, 17, engine=eng)
+        assert n == int(g["n:" + nm]), nm
+        got = np.array([[p[0], p[1], p[2], p[3]] for p in lst[0]], dtype=np.float64).reshape(-1, 4)
+        assert np.array_equal(got, g["kp:" + nm]), nm
+        assert np.array_equal(hm, g["mut:" + nm], equal_nan=True), nm
+        if lst[0]:
+            assert isinstance(lst[0][0][0], np.int64) and isinstance(lst[0][0][2], np.float32) and isinstance(lst[0][0][3], int)
+
+
+def run_api_post(eng, heat_up, paf_up, demo):
+    """demo.py:95-100 through the drop-in API (strided channel views, like the reference caller)."""
+    heat = heat_up.copy()
+    by_type, total = [], 0
+    for k in range(18):
+        total += kp_mod.extract_keypoints(heat[:, :, k], by_type, total, engine=eng)
+    ent, allk = kp_mod.group_keypoints(by_type, paf_up, demo=demo, engine=eng)
+    kp = np.array([[p[0], p[1], p[2], p[3], t] for t, l in enumerate(by_type) for p in l], dtype=np.float64)
+    return heat, kp.reshape(-1, 5), np.asarray(ent, dtype=np.float64), np.asarray(allk, dtype=np.float64)
+
+
+POST = ["p1_small", "p3_small", "p0_empty", "p5_mid", "p10_full", "p4_noisy", "p2_r8"]
+
+
+@pytest.mark.parametrize("name", POST)
+def test_post_api_matches_reference_golden(eng, name):
+    g = np.load(os.path.join(GOLDEN, "post_%s.npz" % name))
+    n, h, w, seed, ratio = [int(v) for v in g["params"]]
+    heat, paf, _ = synth.make_pose_maps(n, h, w, seed, float(g["drop"]), float(g["noise"]))
+    hu = eng.upsample(heat[None], ratio)[0]
+    pu = eng.upsample(paf[None], ratio)[0]
+    for tag, demo in (("demo", True), ("val", False)):
+        hm, kp, ent, allk = run_api_post(eng, hu, pu, demo)
+        assert np.array_equal(kp, g[tag + "_kp"])
+        assert tuple(ent.shape) == tuple(g[tag + "_entries_shape"])
+        assert np.array_equal(ent, g[tag + "_entries"])
+        assert np.array_equal(allk, g[tag + "_allk"])
+
+
+@pytest.mark.parametrize("name", POST)
+def test_post_fused_from_maps_matches_reference_golden(eng, name):
+    """The fused path (no materialised up-sampling) gives the same key-points and poses."""
+    g = np.load(os.path.join(GOLDEN, "post_%s.npz" % name))
+    n, h, w, seed, ratio = [int(v) for v in g["params"]]
+    heat, paf, _ = synth.make_pose_maps(n, h, w, seed, float(g["drop"]), float(g["noise"]))
+    for tag, demo in (("demo", True), ("val", False)):
+        ent, allk, counts = eng.poses_from_maps(heat[None], paf[None], ratio, demo)[0]
+        gk = g[tag + "_kp"]
+        assert np.array_equal(allk, g[tag + "_allk"].reshape(-1, 4))
+        assert np.array_equal(counts, np.bincount(gk[:, 4].astype(int), minlength=18) if len(gk) else np.zeros(18, int))
+        assert np.array_equal(ent.reshape(-1, 20), g[tag + "_entries"].reshape(-1, 20))
+
+
+def test_group_adversarial_golden(eng):
+    g = np.load(os.path.join(GOLDEN, "group_adversarial.npz"))
+    for nm in [k[4:] for k in g.files if k.startswith("paf:")]:
+        kp = g["kp:" + nm]
+        for tag, demo in (("demo", True), ("val", False)):
+            bt = [[] for _ in range(18)]
+            for x, y, s, i, t in kp:
+                bt[int(t)].append((np.int64(x), np.int64(y), np.float32(s), int(i)))
+            ent, allk = kp_mod.group_keypoints(bt, g["paf:" + nm], demo=demo, engine=eng)
+            key = "%s:%s" % (nm, tag)
+            assert tuple(np.asarray(ent).shape) == tuple(g["ent_shape:" + key]), key
+            assert tuple(np.asarray(allk).shape) == tuple(g["allk_shape:" + key]), key
+            assert np.array_equal(np.asarray(ent, dtype=np.float64), g["ent:" + key]), key
+
+
+def test_fused_batch_pipeline_vs_oracle_on_net_outputs():
+    """End to end: frames -> HIP net -> fused HIP post  ==  oracle post on the HIP net's own maps (bit-exact),
+    and the HIP net's maps are within 1e-3 of the oracle net.  Peaky heads so that key-points exist."""
+    net, sd = get_net(1, 1, head_gain=4.0)
+    x = net_input(2, 368, 656, seed=0)
+    res = net.engine.infer_poses(x, 4, demo=True)
+    outs = net(x)
+    total_k = 0
+    for f in range(2):
+        hu = post_ref.upsample_cubic(outs[-2][f].transpose(1, 2, 0), 4)
+        pu = post_ref.upsample_cubic(outs[-1][f].transpose(1, 2, 0), 4)
+        by_type, total = [], 0
+        for k in range(18):
+            total += post_ref.extract_keypoints(hu[:, :, k], by_type, total)
+        ent, allk = post_ref.group_keypoints(by_type, pu, demo=True)
+        e, a, c = res[f]
+        assert np.array_equal(a, np.asarray(allk, dtype=np.float64).reshape(-1, 4))
+        assert np.array_equal(e.reshape(-1, 20), np.asarray(ent, dtype=np.float64).reshape(-1, 20))
+        total_k += total
+    assert total_k > 20
+
+
+def test_capacity_overflow_is_reported():
+    from lwpose_amd._lib import CapacityError
+    e2 = Engine(0)
+    e2.set_capacity(64, 2, 16, 4)
+    heat, paf, _ = synth.make_pose_maps(5, 46, 82, 4, 0.15, 0.02)
+    with pytest.raises(CapacityError):
+        e2.poses_from_maps(heat[None], paf[None], 4, True)
+
+
+def test_drop_in_run_demo_fused_equals_stepwise():
+    from lwpose_amd.demo import run_demo
+    net, _ = get_net(1, 1, head_gain=4.0)
+    frames = synth.make_frames(2, 368, 656, seed0=0)
+    a = [[(p.keypoints.copy(), p.confidence, p.bbox) for p in poses] for _, poses in run_demo(net, frames, 368, False, 0, 0)]
+    b = [[(p.keypoints.copy(), p.confidence, p.bbox) for p in poses] for _, poses in run_demo(net, frames, 368, False, 0, 0, fused=True)]
+    assert len(a) == len(b) == 2
+    for fa, fb in zip(a, b):
+        assert len(fa) == len(fb)
+        for (ka, ca, ba), (kb, cb, bb) in zip(fa, fb):
+            assert np.array_equal(ka, kb) and ca == cb and ba == bb

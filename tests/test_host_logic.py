@@ -1,0 +1,163 @@
+"""CPU: host-side logic — C-ABI exports, parameter table, pre-processing helpers, sharding, and the
+world_size-2 weight-broadcast protocol over gloo (the N>1 path of bench.py without GPUs)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import lwpose_amd  # noqa: F401
+from lwpose_amd import _lib, arch, dist as lwdist, synth
+from lwpose_amd.val import normalize, pad_width, resize_cubic_u8
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "lwpose.h")).read()
+    declared = sorted(set(re.findall(r"\b(lwp_[a-z_0-9]+)\s*\(", hdr)))
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert sorted(declared) == sorted(_lib.EXPORTS)
+
+
+def test_no_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    rc = _lib.lib().lwp_create(0, 1, 128, 19, 38, 0, ctypes.byref(h))
+    assert rc == _lib.LWP_ERR_NOGPU and not h.value
+    with pytest.raises(RuntimeError):
+        from lwpose_amd.runtime import Engine
+        Engine(0)
+
+
+@pytest.mark.parametrize("nref", [0, 1, 3])
+def test_library_param_table_matches_python_and_reference(nref):
+    spec = _lib.param_spec(nref)
+    tab = arch.param_table(nref)
+    assert [k for k, _, _ in spec] == [p.key for p in tab]
+    assert [s for _, s, _ in spec] == [tuple(p.shape) for p in tab]
+    if nref in (1, 3):
+        keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys_nref%d.json" % nref)))
+        assert [k for k, _, _ in spec] == [k for k, _, _ in keys]
+        assert [list(s) for _, s, _ in spec] == [s for _, s, _ in keys]
+
+
+def test_bad_arguments_are_rejected_without_gpu():
+    L = _lib.lib()
+    assert L.lwp_param_count(-1, 128, 19, 38) == _lib.LWP_ERR_ARG
+    h = ctypes.c_void_p()
+    assert L.lwp_create(0, 1, 100, 19, 38, 0, ctypes.byref(h)) == _lib.LWP_ERR_ARG   # channels % 32
+    assert b"multiple of 32" in L.lwp_last_error(None)
+    assert L.lwp_destroy(None) == 0
+
+
+def test_normalize_is_float64_and_exact():
+    img = synth.make_frames(1, 16, 24)[0]
+    out = normalize(img, (128, 128, 128), 1 / 256)
+    assert out.dtype == np.float64                     # NumPy-2 promotion, as in the reference
+    assert np.array_equal(out, (img.astype(np.float64) - 128) / 256)
+    assert np.array_equal(out.astype(np.float32).astype(np.float64), out)
+
+
+def test_pad_width_semantics():
+    img = np.ones((368, 490, 3), np.float64)
+    md = [368, max(490, 368)]
+    out, pad = pad_width(img, 8, (0, 0, 0), md)
+    assert md == [368, 496] and pad == [0, 3, 0, 3] and out.shape == (368, 496, 3)
+    assert out[:, :3].sum() == 0 and out[:, -3:].sum() == 0 and out[:, 3:-3].min() == 1
+    img = np.ones((184, 328, 3), np.float32)
+    md = [368, max(328, 368)]
+    out, pad = pad_width(img, 8, (0, 0, 0), md)      # val.infer at scale 0.5: padded up to base_height
+    assert pad == [92, 20, 92, 20] and out.shape == (368, 368, 3)
+
+
+def test_resize_cubic_u8_identity_and_range():
+    img = synth.make_frames(1, 40, 56)[0]
+    assert np.array_equal(resize_cubic_u8(img, 1.0, 1.0), img)
+    up = resize_cubic_u8(img, 2.0, 2.0)
+    assert up.shape == (80, 112, 3) and up.dtype == np.uint8
+    const = np.full((20, 30, 3), 77, np.uint8)
+    assert np.array_equal(resize_cubic_u8(const, 1.7, 1.7), np.full((34, 51, 3), 77, np.uint8))
+
+
+def test_one_euro_filter_matches_reference_sequence():
+    from lwpose_amd.modules.one_euro_filter import OneEuroFilter
+    ref = json.load(open(os.path.join(GOLDEN, "one_euro.json")))
+    f = OneEuroFilter(freq=15, beta=0.1)
+    assert [float(f(x)) for x in ref["x"]] == ref["y"]
+
+
+def test_pose_bbox_and_tracking_ids():
+    from lwpose_amd.modules.pose import Pose, track_poses
+    kp = -np.ones((18, 2), np.int32)
+    kp[0] = (10, 20); kp[1] = (14, 28); kp[5] = (7, 25)
+    p = Pose(kp, 3.5)
+    assert p.bbox == (7, 20, 8, 9)
+    Pose.last_id = -1
+    a = [Pose(kp.copy(), 3.0)]
+    track_poses([], a)
+    kp2 = kp.copy()
+    b = [Pose(kp2, 2.0)]
+    track_poses(a, b, smooth=True)
+    assert a[0].id == 0 and b[0].id == 0
+
+
+def test_shard_range_partitions_the_batch():
+    for gb in (1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            spans = [lwdist.shard_range(gb, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, numpy as np
+import lwpose_amd
+from lwpose_amd import dist as lwdist
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+torch.distributed.init_process_group("gloo")
+class FakeEngine:                       # stands in for runtime.Engine: the blob protocol without a GPU
+    def __init__(self, fill): self.blob = torch.full((4096,), fill, dtype=torch.uint8)
+    def weights_blob_bytes(self): return self.blob.numel()
+    def export_weights(self, t): t.copy_(self.blob)
+    def import_weights(self, t): self.blob = t.clone()
+eng = FakeEngine(7 if rank == 0 else 0)
+if rank == 0: eng.blob[:16] = torch.arange(16, dtype=torch.uint8)
+n = lwdist.broadcast_weights(eng, rank, world, torch.device("cpu"))
+exp = torch.full((4096,), 7, dtype=torch.uint8); exp[:16] = torch.arange(16, dtype=torch.uint8)
+assert n == 4096 and torch.equal(eng.blob, exp), rank
+lo, hi = lwdist.shard_range(9, rank, world)
+got = lwdist.gather_counts([rank, hi - lo], world)
+assert [int(g[1]) for g in got] == [5, 4] and [int(g[0]) for g in got] == [0, 1]
+# max-over-ranks timing reduction used by bench.py
+t = torch.tensor([1.0 + rank], dtype=torch.float64)
+torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+assert float(t) == 2.0
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_world_size_2_broadcast_and_sharding_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), ROOT]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok 0" in r.stdout and "ok 1" in r.stdout
