@@ -14,6 +14,10 @@ LIB = os.path.join(PKG, "liblwpose_hip.so")
 SOURCES = ["net_graph.cpp", "net_kernels.hip", "post_kernels.hip", "capi.cpp"]
 HEADERS = ["lwp_internal.h", os.path.join("..", "..", "include", "lwpose.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-result", "-DNDEBUG"]
+# the post-processing must reproduce NumPy's separately-rounded float32/float64 arithmetic bit for bit:
+# no FMA contraction anywhere in that translation unit (the in-source pragma alone is not honoured for
+# packed-math fusion by hipcc 7.2)
+EXTRA = {"post_kernels.hip": ["-ffp-contract=off"]}
 
 
 def _stale():
@@ -31,7 +35,7 @@ def build(force=False, verbose=False):
     objs = []
     for s in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(s, []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

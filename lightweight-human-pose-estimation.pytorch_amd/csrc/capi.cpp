@@ -698,6 +698,34 @@ extern "C" int lwp_time_pipeline(lwp_handle h, const float* in_device, int N, in
     return LWP_OK;
 }
 
+extern "C" int lwp_profile_launches(lwp_handle h, const float* in_device, int N, int H, int W, int ratio, int demo, int reps,
+                                    float* ms, int* kclass, int cap, int* n_launches) {
+    if (!h || !in_device || !ms || !kclass || !n_launches || reps <= 0 || cap <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    int rc = prepare_poses(h, N, H, W, ratio);
+    if (rc) return rc;
+    h->last_N = N;
+    for (int i = 0; i < cap; ++i) { ms[i] = 0.f; kclass[i] = -1; }
+    size_t nl = 0;
+    for (int r = 0; r < reps; ++r) {
+        h->profiling = true;
+        h->ev_used = 0;
+        rc = enqueue_poses(h, in_device, N, H, W, ratio, demo, true);
+        h->profiling = false;
+        if (rc) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        nl = h->ev_used / 2;
+        if ((int)nl > cap) return fail(h, LWP_ERR_ARG, "launch arrays too small");
+        for (size_t i = 0; i < nl; ++i) {
+            float t = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&t, h->ev[2 * i], h->ev[2 * i + 1]));
+            ms[i] += t / (float)reps;
+            kclass[i] = h->ev_class[i];
+        }
+    }
+    *n_launches = (int)nl;
+    return LWP_OK;
+}
+
 extern "C" int lwp_profile_classes(lwp_handle h, const float* in_device, int N, int H, int W, int ratio, int demo, int reps,
                                    float* ms, int* launches) {
     if (!h || !in_device || !ms || !launches || reps <= 0) return fail(h, LWP_ERR_ARG, "bad argument");

@@ -224,6 +224,19 @@ class Engine(object):
         self._last_N = N
         return ms.value
 
+    def profile_launches(self, x_cuda, reps=5, upsample_ratio=4, demo=True):
+        """[(name, class, ms)] per launch in issue order (HIP events around every launch)."""
+        N, _, H, W = x_cuda.shape
+        cap = 256
+        ms = (C.c_float * cap)()
+        kc = (C.c_int * cap)()
+        n = C.c_int()
+        check(lib().lwp_profile_launches(self.h.ptr, x_cuda.data_ptr(), N, H, W, upsample_ratio, 1 if demo else 0, reps, ms, kc, cap, C.byref(n)), self.h.ptr)
+        layers = self.layers()
+        post = ["reset_ws", "find_peaks", "nms", "score_pairs", "assemble"]
+        names = [l["name"] for l in layers] + post
+        return [(names[i] if i < len(names) else "launch%d" % i, kc[i], ms[i]) for i in range(n.value)]
+
     def profile_classes(self, x_cuda, reps=5, upsample_ratio=4, demo=True):
         N, _, H, W = x_cuda.shape
         ms = (C.c_float * 6)()

@@ -147,7 +147,7 @@ torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
 assert float(t) == 2.0
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
-print("ok", rank)
+open(os.path.join(sys.argv[2], "ok_%d" % rank), "w").write("ok")
 '''
 
 
@@ -156,8 +156,8 @@ def test_world_size_2_broadcast_and_sharding_over_gloo(tmp_path):
     script.write_text(_WORKER)
     port = 29500 + os.getpid() % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script), ROOT]
+           "--master-port", str(port), str(script), ROOT, str(tmp_path)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "ok 0" in r.stdout and "ok 1" in r.stdout
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
