@@ -159,6 +159,8 @@ int lwp_synchronize(lwp_handle h);
 int lwp_layer_count(lwp_handle h);
 int lwp_layer_info(lwp_handle h, int layer_index, char* name, int name_cap, int* kind, int* cin, int* cout,
                    int* ksize, int* stride, int* dilation);
+/* average device time (ms) of `iters` back-to-back launches of one layer on the current buffers */
+int lwp_debug_time_layer(lwp_handle h, int layer_index, int N, int H, int W, int iters, float* ms_avg);
 int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int H, int W, int layer_index,
                            float* dst, size_t dst_floats, int out_dims[4]);
 

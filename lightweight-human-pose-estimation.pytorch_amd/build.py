@@ -17,7 +17,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-u
 # the post-processing must reproduce NumPy's separately-rounded float32/float64 arithmetic bit for bit:
 # no FMA contraction anywhere in that translation unit (the in-source pragma alone is not honoured for
 # packed-math fusion by hipcc 7.2)
-EXTRA = {"post_kernels.hip": ["-ffp-contract=off"]}
+EXTRA = {"post_kernels.hip": ["-ffp-contract=off"] + (["-DLWP_ASM_STAMPS"] if os.environ.get("LWP_ASM_STAMPS") else [])}
 
 
 def _stale():

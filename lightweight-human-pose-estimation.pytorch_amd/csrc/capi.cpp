@@ -17,6 +17,7 @@ struct lwp_context {
     int dtype = LWP_F32;
     Graph g;
     float* d_blob = nullptr;
+    float* d_zeros = nullptr;
     bool weights_loaded = false;
     // activations for the current (N, H, W)
     int cur_N = 0, cur_H = 0, cur_W = 0;
@@ -115,6 +116,9 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
     if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("init_cubic_tables: ") + hipGetErrorString(e)); }
     e = hipMalloc((void**)&h->d_blob, h->g.blob_floats * sizeof(float));
     if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("hipMalloc(blob): ") + hipGetErrorString(e)); }
+    e = hipMalloc((void**)&h->d_zeros, 4096);
+    if (e == hipSuccess) e = hipMemset(h->d_zeros, 0, 4096);
+    if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("hipMalloc(zeros): ") + hipGetErrorString(e)); }
     h->bufs.assign(h->g.bufs.size(), nullptr);
     h->d_outs.assign(2 * (1 + nref), nullptr);
     h->d_outs_bytes.assign(2 * (1 + nref), 0);
@@ -125,7 +129,8 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
 static void free_ws(lwp_context* h) {
     PostWorkspace& w = h->ws;
     void* ptrs[] = {w.peak_count, w.peak_key, w.peak_val, w.kpt_count, w.kpt_xy, w.kpt_score, w.conn_count,
-                    w.conn_ij, w.conn_ratio, w.flags, w.entries, w.n_entries, w.kpts_out};
+                    w.conn_ij, w.conn_ratio, w.flags, w.entries, w.n_entries, w.kpts_out, w.sel_count, w.sel_ij, w.sel_r,
+                    w.entries_work, w.sel_sa, w.sel_sb};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = PostWorkspace();
 }
@@ -140,6 +145,7 @@ extern "C" int lwp_destroy(lwp_handle h) {
     if (h->d_tmp) (void)hipFree(h->d_tmp);
     if (h->d_tmp2) (void)hipFree(h->d_tmp2);
     if (h->d_blob) (void)hipFree(h->d_blob);
+    if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     free_ws(h);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -151,8 +157,8 @@ extern "C" int lwp_destroy(lwp_handle h) {
 extern "C" int lwp_set_capacity(lwp_handle h, int max_peaks, int max_kpts, int max_conn, int max_entries) {
     if (!h) return LWP_ERR_ARG;
     if (max_peaks < 64 || max_peaks > 8192 || max_kpts < 1 || max_kpts > 1024 || max_conn < 1 || max_conn > (1 << 20) ||
-        max_entries < 1 || max_entries > 640)
-        return fail(h, LWP_ERR_ARG, "capacity out of range (peaks 64..8192, kpts 1..1024, conns 1..2^20, entries 1..640)");
+        max_entries < 1 || max_entries > 65535)
+        return fail(h, LWP_ERR_ARG, "capacity out of range (peaks 64..8192, kpts 1..1024, conns 1..2^20, entries 1..65535)");
     (void)hipSetDevice(h->device);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     free_ws(h);
@@ -242,10 +248,17 @@ static int ensure_ws(lwp_context* h, int N) {
     WS_ALLOC(conn_ratio, (size_t)N * 19 * c.max_conn, double);
     WS_ALLOC(flags, (size_t)N * 4, unsigned long long);
     WS_ALLOC(entries, (size_t)N * c.max_entries * 20, double);
+    WS_ALLOC(entries_work, (size_t)N * c.max_entries * 20, double);
+    WS_ALLOC(sel_count, N * 19, int);
+    WS_ALLOC(sel_ij, (size_t)N * 19 * c.max_kpts, int);
+    WS_ALLOC(sel_r, (size_t)N * 19 * c.max_kpts, double);
+    WS_ALLOC(sel_sa, (size_t)N * 19 * c.max_kpts, float);
+    WS_ALLOC(sel_sb, (size_t)N * 19 * c.max_kpts, float);
     WS_ALLOC(n_entries, N, int);
     WS_ALLOC(kpts_out, (size_t)N * 18 * c.max_kpts * 4, double);
 #undef WS_ALLOC
     w.N = N;
+    HIP_TRY(h, launch_reset_ws(N, w, h->stream));
     return LWP_OK;
 }
 
@@ -289,37 +302,44 @@ static int prof_end(lwp_context* h) {
     } while (0)
 
 // ---------------------------------------------------------------------------------------------- forward
+static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int N, int H, int W, float* const* d_outs_nchw) {
+    const Graph& g = h->g;
+    const float* wts = h->d_blob + l.w_off;
+    const float* bias = h->d_blob + l.b_off;
+    int dh, dw;
+    level_dims(H, W, g.bufs[l.dst.buf].level, &dh, &dw);
+    float* dst = h->bufs[l.dst.buf] + l.dst.coff;
+    if (l.kind == L_STEM) {
+        StemParams p{d_in, wts, bias, dst, N, H, W, dh, dw};
+        LAUNCH(h, KC_STEM, launch_stem(p, h->stream));
+    } else if (l.kind == L_DW) {
+        int sh, sw;
+        level_dims(H, W, g.bufs[l.src.buf].level, &sh, &sw);
+        DwParams p{h->bufs[l.src.buf] + l.src.coff, l.src.ld, wts, bias, dst, l.dst.ld, N, sh, sw, dh, dw, l.cin, l.stride, l.dil, l.act};
+        LAUNCH(h, KC_DW, launch_dw(p, h->stream));
+    } else {
+        GemmParams p;
+        p.in = h->bufs[l.src.buf] + l.src.coff; p.in_ld = l.src.ld;
+        p.w = wts; p.bias = bias;
+        p.out = dst; p.out_ld = l.dst.ld;
+        p.res = l.res.buf >= 0 ? h->bufs[l.res.buf] + l.res.coff : nullptr; p.res_ld = l.res.ld;
+        p.out_nchw = (l.out_index >= 0 && d_outs_nchw) ? d_outs_nchw[l.out_index] : nullptr;
+        p.zeros = h->d_zeros;
+        p.N = N; p.H = dh; p.W = dw;
+        p.cin_pad = l.cin_pad; p.cout = l.cout; p.cout_pad = l.cout_pad; p.ks = l.ks; p.dil = l.dil; p.act = l.act;
+        LAUNCH(h, l.ks == 1 ? KC_PW : KC_C3, launch_gemm(p, h->stream));
+    }
+    return LWP_OK;
+}
+
 // enqueue every layer on the handle's stream.  d_outs_nchw: 2*(1+nref) device pointers or null.
 static int enqueue_forward(lwp_context* h, const float* d_in, int N, int H, int W, float* const* d_outs_nchw,
                            int max_layers = 1 << 30) {
-    const Graph& g = h->g;
     int li = 0;
-    for (const Layer& l : g.layers) {
+    for (const Layer& l : h->g.layers) {
         if (li++ >= max_layers) break;
-        const float* wts = h->d_blob + l.w_off;
-        const float* bias = h->d_blob + l.b_off;
-        int dh, dw;
-        level_dims(H, W, g.bufs[l.dst.buf].level, &dh, &dw);
-        float* dst = h->bufs[l.dst.buf] + l.dst.coff;
-        if (l.kind == L_STEM) {
-            StemParams p{d_in, wts, bias, dst, N, H, W, dh, dw};
-            LAUNCH(h, KC_STEM, launch_stem(p, h->stream));
-        } else if (l.kind == L_DW) {
-            int sh, sw;
-            level_dims(H, W, g.bufs[l.src.buf].level, &sh, &sw);
-            DwParams p{h->bufs[l.src.buf] + l.src.coff, l.src.ld, wts, bias, dst, l.dst.ld, N, sh, sw, dh, dw, l.cin, l.stride, l.dil, l.act};
-            LAUNCH(h, KC_DW, launch_dw(p, h->stream));
-        } else {
-            GemmParams p;
-            p.in = h->bufs[l.src.buf] + l.src.coff; p.in_ld = l.src.ld;
-            p.w = wts; p.bias = bias;
-            p.out = dst; p.out_ld = l.dst.ld;
-            p.res = l.res.buf >= 0 ? h->bufs[l.res.buf] + l.res.coff : nullptr; p.res_ld = l.res.ld;
-            p.out_nchw = (l.out_index >= 0 && d_outs_nchw) ? d_outs_nchw[l.out_index] : nullptr;
-            p.N = N; p.H = dh; p.W = dw;
-            p.cin_pad = l.cin_pad; p.cout = l.cout; p.cout_pad = l.cout_pad; p.ks = l.ks; p.dil = l.dil; p.act = l.act;
-            LAUNCH(h, l.ks == 1 ? KC_PW : KC_C3, launch_gemm(p, h->stream));
-        }
+        int rc = enqueue_layer(h, l, d_in, N, H, W, d_outs_nchw);
+        if (rc) return rc;
     }
     return LWP_OK;
 }
@@ -432,6 +452,7 @@ extern "C" int lwp_extract_keypoints(lwp_handle h, float* heatmap, int H, int W,
     HIP_TRY(h, hipMemcpyAsync(h_sc, h->ws.kpt_score, (size_t)h->caps.max_kpts * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(&n, h->ws.kpt_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(&fl, h->ws.flags, sizeof(fl), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, launch_reset_ws(1, h->ws, h->stream));   // leave the append counters zeroed (the fused path relies on it)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) heatmap[y * row_stride + x * pix_stride] = hs[(size_t)y * W + x];
@@ -524,6 +545,7 @@ extern "C" int lwp_group_keypoints(lwp_handle h, const double* kpts, const int* 
     HIP_TRY(h, hipStreamSynchronize(h->stream));   // the host vectors above go out of scope
     MapView v{d_paf, 0, (int64_t)W * NPc, (int64_t)NPc, 1, H, W};
     LAUNCH(h, KC_POST, launch_score_pairs(v, 1, 1, demo, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_match(1, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_assemble(1, h->ws, h->stream));
     std::vector<int> kc(18);
     std::vector<double> kout((size_t)std::max(total, 1) * 4);
@@ -539,10 +561,10 @@ static int enqueue_poses(lwp_context* h, const float* d_in, int N, int H, int W,
     const float* cat = h->bufs[g.cat_buf];
     MapView heat{cat + g.C, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
     MapView paf{cat + g.C + g.NH, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
-    LAUNCH(h, KC_POST, launch_reset_ws(N, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_find_peaks(heat, N, 18, ratio, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_nms(N, 18, fh * ratio, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_score_pairs(paf, N, ratio, demo, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_match(N, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_assemble(N, h->ws, h->stream));
     return LWP_OK;
 }
@@ -613,10 +635,10 @@ extern "C" int lwp_poses_from_maps(lwp_handle h, const float* heat, const float*
     const int64_t hw = (int64_t)hs * ws;
     MapView hv{d_heat, (int64_t)h->g.NH * hw, (int64_t)ws, 1, hw, hs, ws};
     MapView pv{d_paf, (int64_t)h->g.NP * hw, (int64_t)ws, 1, hw, hs, ws};
-    LAUNCH(h, KC_POST, launch_reset_ws(N, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_find_peaks(hv, N, 18, ratio, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_nms(N, 18, hs * ratio, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_score_pairs(pv, N, ratio, demo, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_match(N, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_assemble(N, h->ws, h->stream));
     h->last_N = N;
     return fetch_results(h, N, kpt_counts, kpts, kpt_cap, entries, entry_cap, n_entries);
@@ -665,6 +687,32 @@ extern "C" int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int 
     HIP_TRY(h, hipMemcpyAsync(dst, h->d_tmp, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     out_dims[0] = N; out_dims[1] = l.cout; out_dims[2] = dh; out_dims[3] = dw;
+    return LWP_OK;
+}
+
+extern "C" int lwp_debug_time_layer(lwp_handle h, int idx, int N, int H, int W, int iters, float* ms_avg) {
+    if (!h || !ms_avg || idx < 0 || idx >= (int)h->g.layers.size() || iters <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    int rc = check_frame_shape(h, N, H, W);
+    if (rc) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = ensure_activations(h, N, H, W);
+    if (rc) return rc;
+    rc = ensure_dev(h, &h->d_in, &h->d_in_bytes, (size_t)N * 3 * H * W * sizeof(float));
+    if (rc) return rc;
+    const Layer& l = h->g.layers[idx];
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) { rc = enqueue_layer(h, l, h->d_in, N, H, W, nullptr); if (rc) return rc; }
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < iters; ++i) { rc = enqueue_layer(h, l, h->d_in, N, H, W, nullptr); if (rc) return rc; }
+    HIP_TRY(h, hipEventRecord(e1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+    *ms_avg = ms / (float)iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return LWP_OK;
 }
 

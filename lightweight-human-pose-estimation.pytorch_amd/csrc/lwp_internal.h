@@ -89,6 +89,7 @@ struct GemmParams {
     float* out; int out_ld;
     const float* res; int res_ld;    // may be null
     float* out_nchw;                 // may be null: N x cout x H x W
+    const float* zeros;              // >= 16 bytes of zeros (source of out-of-image taps)
     int N, H, W, cin_pad, cout, cout_pad, ks, dil, act;
 };
 hipError_t launch_stem(const StemParams& p, hipStream_t s);
@@ -118,6 +119,12 @@ struct PostWorkspace {    // device buffers, sized for (N frames, caps)
     unsigned long long* flags = nullptr;  // [N*4]  0: overflow bits (1 peaks, 2 kpts, 4 conns/entries),
                                           //        1: min order of a pair whose mid-point test failed,
                                           //        2: min order of a pair whose mid-point test passed
+    int* sel_count = nullptr;       // [N*19]  connections picked by the greedy matching
+    int* sel_ij = nullptr;          // [N*19*max_kpts]
+    double* sel_r = nullptr;        // [N*19*max_kpts]
+    float* sel_sa = nullptr;        // [N*19*max_kpts] score of the connection's first key-point
+    float* sel_sb = nullptr;        // [N*19*max_kpts] score of its second key-point
+    double* entries_work = nullptr; // [N*max_entries*20] scratch when the entries do not fit LDS
     double* entries = nullptr;      // [N*max_entries*20]
     int* n_entries = nullptr;       // [N]
     double* kpts_out = nullptr;     // [N*18*max_kpts*4]
@@ -130,6 +137,7 @@ hipError_t launch_upsample(const MapView& src, int N, int C, int ratio, float* d
 hipError_t launch_find_peaks(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_nms(int N, int ntypes, int Hfull, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_score_pairs(const MapView& paf, int N, int ratio, int demo, PostWorkspace& ws, hipStream_t s);
+hipError_t launch_match(int N, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_assemble(int N, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_threshold_inplace(float* map, int64_t n, hipStream_t s);
 hipError_t launch_nchw_from_nhwc(const float* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s);

@@ -8,6 +8,9 @@
 //                 (v_mfma_f32_32x32x2_f32: exact f32 fmaf chains, 157 TFLOP/s peak).  Tiles are
 //                 register-staged into padded LDS rows (36 floats: conflict-free ds_read_b128),
 //                 double-buffered, one barrier per 32-deep K step.
+#include <cstdio>
+#include <cstdlib>
+
 #include "lwp_internal.h"
 
 namespace lwp {
@@ -132,29 +135,36 @@ hipError_t launch_dw(const DwParams& p, hipStream_t s) {
 // ---------------------------------------------------------------------------------------- implicit GEMM
 // out[m][n] = act(sum_{tap,c} in[pix(m)+off(tap)][c] * w[tap][n][c] + bias[n]) (+ res[m][n])
 //   m: output pixel (N*H*W, stride-1 convs only), n: output channel, K = taps * cin_pad.
-// Workgroup tile BM x BN, WM x WN waves, each wave a 32x32 accumulator (v_mfma_f32_32x32x2_f32).
+// Workgroup tile BM x BN; (BM/32) x (BN/32) waves each own a 32x32 accumulator (v_mfma_f32_32x32x2_f32),
+// replicated KS times: K-slice group g walks K steps g, g+KS, ... with its own double-buffered LDS
+// tiles, and the KS partial accumulators are summed through LDS in a fixed order at the end
+// (intra-workgroup split-K: at batch 1 the M x N tile count alone cannot fill 1024 SIMDs).
 // K is walked in steps of 32 channels inside one tap.  LDS rows are [row][32 + 4 pad] floats: a lane
 // (row r = lane&31, half h = lane>>5) reads 4 consecutive k with one ds_read_b128 at k = 8s + 4h; MFMA
 // (s,t) then contracts k in {8s+t, 8s+4+t} on the A and the B side alike (any k order is a valid GEMM).
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int BM, int BN>
-__global__ void __launch_bounds__((BM / 32) * (BN / 32) * 64) gemm_kernel(GemmParams p) {
+template <int BM, int BN, int KS>
+__global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(GemmParams p) {
     constexpr int WM = BM / 32, WN = BN / 32;
-    constexpr int NT = WM * WN * 64;
+    constexpr int GW = WM * WN;                     // waves per K-slice group
+    constexpr int GT = GW * 64;                     // threads per group
     constexpr int A_CHUNKS = BM * (BK / 4);         // 16-byte chunks per A tile
     constexpr int B_CHUNKS = BN * (BK / 4);
-    constexpr int A_PER = (A_CHUNKS + NT - 1) / NT;
-    constexpr int B_PER = (B_CHUNKS + NT - 1) / NT;
-    static_assert(A_CHUNKS % NT == 0 && B_CHUNKS % NT == 0, "tile/threads mismatch");
+    constexpr int A_PER = A_CHUNKS / GT;
+    constexpr int B_PER = B_CHUNKS / GT;
+    static_assert(A_CHUNKS % GT == 0 && B_CHUNKS % GT == 0, "tile/threads mismatch");
+    constexpr int TILE_FLOATS = 2 * (BM + BN) * LDS_LD;   // one group's double-buffered A+B tiles
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                               // [2][BM][LDS_LD]
-    float* Bs = smem + 2 * BM * LDS_LD;             // [2][BN][LDS_LD]
-
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int g = tid / GT;                         // K-slice group (wave-uniform)
+    const int t = tid - g * GT;
+    float* As = smem + g * TILE_FLOATS;             // [2][BM][LDS_LD]
+    float* Bs = As + 2 * BM * LDS_LD;               // [2][BN][LDS_LD]
+
+    const int lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
 
@@ -177,7 +187,7 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * 64) gemm_kernel(GemmPa
     bool a_ok[A_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
-        const int ch = tid + i * NT;
+        const int ch = t + i * GT;
         a_row[i] = ch / (BK / 4);
         a_col[i] = (ch % (BK / 4)) * 4;
         const int64_t m = m0 + a_row[i];
@@ -185,14 +195,15 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * 64) gemm_kernel(GemmPa
         const int64_t mm = a_ok[i] ? m : 0;
         a_x[i] = (int)(mm % p.W);
         a_y[i] = (int)((mm / p.W) % p.H);
-        a_base[i] = mm * p.in_ld;
+        a_base[i] = mm * p.in_ld + a_col[i];
     }
-    int b_row[B_PER], b_col[B_PER];
+    int b_off[B_PER], b_lds[B_PER];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
-        const int ch = tid + i * NT;
-        b_row[i] = ch / (BK / 4);
-        b_col[i] = (ch % (BK / 4)) * 4;
+        const int ch = t + i * GT;
+        const int row = ch / (BK / 4), col = (ch % (BK / 4)) * 4;
+        b_off[i] = row * p.cin_pad + col;
+        b_lds[i] = row * LDS_LD + col;
     }
 
     const int ksteps_per_tap = p.cin_pad / BK;
@@ -205,17 +216,19 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * 64) gemm_kernel(GemmPa
         const int c0 = (step - tap * ksteps_per_tap) * BK;
         int dy = 0, dx = 0;
         if (p.ks == 3) { dy = (tap / 3 - 1) * p.dil; dx = (tap % 3 - 1) * p.dil; }
+        const int64_t shift = ((int64_t)dy * p.W + dx) * p.in_ld + c0;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
             const bool ok = a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *(const f32x4*)(p.in + a_base[i] + ((int64_t)dy * p.W + dx) * p.in_ld + c0 + a_col[i]);
-            a_reg[i] = v;
+            // taps outside the image read a zero page: the select is on the ADDRESS, so the loaded value goes
+            // to LDS untouched and its s_waitcnt lands after the MFMA block (latency hidden behind compute)
+            const float* src = ok ? p.in + a_base[i] + shift : p.zeros;
+            a_reg[i] = *(const f32x4*)src;
         }
         const float* wt = p.w + ((int64_t)tap * p.cout_pad + n0) * p.cin_pad + c0;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) b_reg[i] = *(const f32x4*)(wt + (int64_t)b_row[i] * p.cin_pad + b_col[i]);
+        for (int i = 0; i < B_PER; ++i) b_reg[i] = *(const f32x4*)(wt + b_off[i]);
     };
     auto store_step = [&](int buf) {
         float* a = As + buf * BM * LDS_LD;
@@ -223,29 +236,46 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * 64) gemm_kernel(GemmPa
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) *(f32x4*)(a + a_row[i] * LDS_LD + a_col[i]) = a_reg[i];
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) *(f32x4*)(b + b_row[i] * LDS_LD + b_col[i]) = b_reg[i];
+        for (int i = 0; i < B_PER; ++i) *(f32x4*)(b + b_lds[i]) = b_reg[i];
     };
 
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    load_step(0);
-    store_step(0);
+    const int iters = (nsteps + KS - 1) / KS;
+    if (g < nsteps) { load_step(g); store_step(0); }
     __syncthreads();
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        if (step + 1 < nsteps) load_step(step + 1);
-        const float* a = As + buf * BM * LDS_LD + (wm * 32 + r) * LDS_LD + 4 * h;
-        const float* b = Bs + buf * BN * LDS_LD + (wn * 32 + r) * LDS_LD + 4 * h;
+    for (int it = 0; it < iters; ++it) {
+        const int cur = g + it * KS, nxt = cur + KS;
+        const int buf = it & 1;
+        if (nxt < nsteps) load_step(nxt);
+        if (cur < nsteps) {
+            const float* a = As + buf * BM * LDS_LD + (wm * 32 + r) * LDS_LD + 4 * h;
+            const float* b = Bs + buf * BN * LDS_LD + (wn * 32 + r) * LDS_LD + 4 * h;
 #pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            const f32x4 av = *(const f32x4*)(a + 8 * s);
-            const f32x4 bv = *(const f32x4*)(b + 8 * s);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            for (int s = 0; s < BK / 8; ++s) {
+                const f32x4 av = *(const f32x4*)(a + 8 * s);
+                const f32x4 bv = *(const f32x4*)(b + 8 * s);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            }
         }
-        if (step + 1 < nsteps) store_step(buf ^ 1);
+        if (nxt < nsteps) store_step(buf ^ 1);
         __syncthreads();
+    }
+
+    if (KS > 1) {   // fixed-order reduction of the K-slice partials through LDS (tiles are dead after the last barrier)
+        float* red = smem;                          // [KS-1][GW][16][64]
+        if (g > 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(((g - 1) * GW + wave) * 16 + i) * 64 + lane] = acc[i];
+        }
+        __syncthreads();
+        if (g > 0) return;
+#pragma unroll
+        for (int gg = 1; gg < KS; ++gg)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += red[(((gg - 1) * GW + wave) * 16 + i) * 64 + lane];
     }
 
     // epilogue: lane holds column n = n0 + wn*32 + r, rows (i&3) + 8*(i>>2) + 4*h of the wave tile
@@ -269,22 +299,66 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * 64) gemm_kernel(GemmPa
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int KS>
 static hipError_t launch_gemm_t(const GemmParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.H * p.W;
     const int64_t tiles = ((M + BM - 1) / BM) * (p.cout_pad / BN);
-    constexpr int NT = (BM / 32) * (BN / 32) * 64;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN>), dim3((unsigned)tiles), dim3(NT), lds, s, p);
+    constexpr int NT = (BM / 32) * (BN / 32) * KS * 64;
+    size_t lds = (size_t)KS * 2 * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t red = (size_t)(KS - 1) * (BM / 32) * (BN / 32) * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, KS>), dim3((unsigned)tiles), dim3(NT), lds, s, p);
     return hipGetLastError();
+}
+
+struct GemmCfg { int bm, bn, ks; };
+static bool parse_cfg(const char* env, GemmCfg* c) {
+    if (!env) return false;
+    return sscanf(env, "%d,%d,%d", &c->bm, &c->bn, &c->ks) == 3;
+}
+
+static hipError_t dispatch_gemm(const GemmParams& p, hipStream_t s, GemmCfg c) {
+#define GEMM_CASE(BM_, BN_, KS_) \
+    if (c.bm == BM_ && c.bn == BN_ && c.ks == KS_) return launch_gemm_t<BM_, BN_, KS_>(p, s);
+    GEMM_CASE(32, 64, 1) GEMM_CASE(32, 64, 2) GEMM_CASE(32, 64, 4)
+    GEMM_CASE(64, 64, 1) GEMM_CASE(64, 64, 2) GEMM_CASE(64, 64, 4)
+    GEMM_CASE(64, 128, 1) GEMM_CASE(64, 128, 2)
+    GEMM_CASE(128, 128, 1)
+    GEMM_CASE(32, 32, 4) GEMM_CASE(32, 32, 8)
+#undef GEMM_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.H * p.W;
+    const int nsteps = p.ks * p.ks * (p.cin_pad / BK);
+    GemmCfg c{64, 64, 1};
+    // experiments: LWP_GEMM_C3 / LWP_GEMM_PW = "BM,BN,KS" override the heuristic for dense-3x3 / 1x1 layers
+    static const char* env_c3 = getenv("LWP_GEMM_C3");
+    static const char* env_pw = getenv("LWP_GEMM_PW");
+    GemmCfg o;
+    if (parse_cfg(p.ks == 3 ? env_c3 : env_pw, &o) && (p.cout_pad % o.bn) == 0) return dispatch_gemm(p, s, o);
+    // heuristic (from tools/gemm_sweep.py on the real layer shapes): with >= ~1.5 waves of 64x64 tiles per CU use
+    // them (split K in two while the grid is still short); otherwise 32-row tiles and split K four ways inside
+    // the workgroup so that every SIMD of every CU holds waves; narrow heads (N padded to 64) with a long K go
+    // to 32x32 tiles with an 8-way split.
     const int64_t t64 = ((M + 63) / 64) * (p.cout_pad / 64);
-    // small problems: 32-row tiles double the workgroup count so more of the 256 CUs have work
-    if (t64 < 512) return launch_gemm_t<32, 64>(p, s);
-    return launch_gemm_t<64, 64>(p, s);
+    const int64_t t32 = ((M + 31) / 32) * (p.cout_pad / 64);
+    if (t64 >= 400) {
+        c = GemmCfg{64, 64, (t64 < 1024 && nsteps >= 8) ? 2 : 1};
+    } else if (p.cout_pad == 64 && nsteps >= 16) {
+        c = GemmCfg{32, 32, 8};
+    } else {
+        c = GemmCfg{32, 64, nsteps >= 4 ? 4 : (nsteps >= 2 ? 2 : 1)};
+        if (t32 >= 1024 && c.ks > 2) c.ks = 2;
+    }
+    return dispatch_gemm(p, s, c);
 }
 
 // ---------------------------------------------------------------------------------------- layout helper

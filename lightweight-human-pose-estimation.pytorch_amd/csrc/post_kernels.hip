@@ -119,7 +119,7 @@ hipError_t launch_threshold_inplace(float* map, int64_t n, hipStream_t s) {
 __global__ void __launch_bounds__(256) reset_ws_kernel(int N, PostWorkspace ws) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N * 18) { ws.peak_count[i] = 0; ws.kpt_count[i] = 0; }
-    if (i < N * 19) ws.conn_count[i] = 0;
+    if (i < N * 19) { ws.conn_count[i] = 0; ws.sel_count[i] = 0; }
     if (i < N) {
         ws.n_entries[i] = 0;
         ws.flags[i * 4 + 0] = 0ull; ws.flags[i * 4 + 1] = ~0ull; ws.flags[i * 4 + 2] = ~0ull; ws.flags[i * 4 + 3] = 0ull;
@@ -132,44 +132,99 @@ hipError_t launch_reset_ws(int N, PostWorkspace& ws, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ peaks
 // keypoints.py:17-30: threshold, zero border, strict > against the 4 neighbours.
-// One 16x16 tile of full-res pixels per workgroup, halo of 1 staged through LDS.
-constexpr int PT = 16;
-__global__ void __launch_bounds__(PT * PT) find_peaks_kernel(MapView heat, int ratio, PostWorkspace ws) {
-    __shared__ float tile[PT + 2][PT + 3];
-    const int Hf = heat.h * ratio, Wf = heat.w * ratio;
-    const int tiles_x = (Wf + PT - 1) / PT;
-    const int tx0 = (blockIdx.x % tiles_x) * PT, ty0 = (blockIdx.x / tiles_x) * PT;
+// One PTH x PTW tile of full-res pixels per workgroup.  For R = 4 / 8 the up-sampled values (tile + halo 1) are
+// produced separably through LDS from the (PTH/R+6) x (PTW/R+6) low-res patch: horizontal pass, then vertical
+// pass — the same two-pass arithmetic as sample_map / upsample_kernel, so the bits are identical, but with ~10x
+// fewer global loads and no per-pixel index arithmetic.  R = 1: the map is already full resolution.
+constexpr int PTH = 16, PTW = 32;
+template <int R>
+__global__ void __launch_bounds__(256) find_peaks_kernel(MapView heat, PostWorkspace ws) {
+    constexpr int LH = PTH / R + 6, LW = PTW / R + 6;
+    __shared__ float lo[R == 1 ? 1 : LH][R == 1 ? 1 : LW + 1];
+    __shared__ float hz[R == 1 ? 1 : LH][R == 1 ? 1 : PTW + 3];
+    __shared__ float tile[PTH + 2][PTW + 3];
+    const int Hf = heat.h * R, Wf = heat.w * R;
+    const int tiles_x = (Wf + PTW - 1) / PTW;
+    const int X0 = (blockIdx.x % tiles_x) * PTW, Y0 = (blockIdx.x / tiles_x) * PTH;
     const int t = blockIdx.y, n = blockIdx.z;
     const int tid = threadIdx.x;
-    for (int i = tid; i < (PT + 2) * (PT + 2); i += PT * PT) {
-        const int ly = i / (PT + 2), lx = i % (PT + 2);
-        const int Y = ty0 + ly - 1, X = tx0 + lx - 1;
-        float v = 0.f;
-        if (Y >= 0 && Y < Hf && X >= 0 && X < Wf) {
-            v = sample_map(heat, n, t, Y, X, ratio);
-            if (v < 0.1f) v = 0.f;
+    const float* base = heat.base + (int64_t)n * heat.ns + (int64_t)t * heat.cs;
+    if (blockIdx.x == 0 && t == 0 && tid < 4)   // flags are only touched by the kernels that follow in the stream
+        ws.flags[n * 4 + tid] = (tid == 1 || tid == 2) ? ~0ull : 0ull;
+    if (R == 1) {
+        for (int i = tid; i < (PTH + 2) * (PTW + 2); i += 256) {
+            const int ly = i / (PTW + 2), lx = i % (PTW + 2);
+            const int Y = Y0 + ly - 1, X = X0 + lx - 1;
+            float v = 0.f;
+            if (Y >= 0 && Y < Hf && X >= 0 && X < Wf) {
+                v = base[(int64_t)Y * heat.ys + (int64_t)X * heat.xs];
+                if (v < 0.1f) v = 0.f;
+            }
+            tile[ly][lx] = v;
         }
-        tile[ly][lx] = v;
+    } else {
+        const CubicTable& ct = g_cubic[R == 4 ? 0 : 1];
+        const int ly0 = Y0 / R - 3, lx0 = X0 / R - 3;
+        for (int i = tid; i < LH * LW; i += 256) {
+            const int j = i / LW, k = i % LW;
+            lo[j][k] = base[(int64_t)clampi(ly0 + j, 0, heat.h - 1) * heat.ys + (int64_t)clampi(lx0 + k, 0, heat.w - 1) * heat.xs];
+        }
+        __syncthreads();
+        for (int i = tid; i < LH * (PTW + 2); i += 256) {        // horizontal pass
+            const int j = i / (PTW + 2), lx = i % (PTW + 2);
+            const int X = X0 + lx - 1;
+            float a = 0.f;
+            if (X >= 0 && X < Wf) {
+                const int qx = X / R, px = X - qx * R;
+                const int c = qx + ct.off[px] - 1 - lx0;            // patch column of the first tap
+                a = __fmul_rn(lo[j][c], ct.w[px][0]);
+                a = __fadd_rn(a, __fmul_rn(lo[j][c + 1], ct.w[px][1]));
+                a = __fadd_rn(a, __fmul_rn(lo[j][c + 2], ct.w[px][2]));
+                a = __fadd_rn(a, __fmul_rn(lo[j][c + 3], ct.w[px][3]));
+            }
+            hz[j][lx] = a;
+        }
+        __syncthreads();
+        for (int i = tid; i < (PTH + 2) * (PTW + 2); i += 256) {  // vertical pass + threshold
+            const int ly = i / (PTW + 2), lx = i % (PTW + 2);
+            const int Y = Y0 + ly - 1, X = X0 + lx - 1;
+            float v = 0.f;
+            if (Y >= 0 && Y < Hf && X >= 0 && X < Wf) {
+                const int qy = Y / R, py = Y - qy * R;
+                const int rr = qy + ct.off[py] - 1 - ly0;
+                v = __fmul_rn(hz[rr][lx], ct.w[py][0]);
+                v = __fadd_rn(v, __fmul_rn(hz[rr + 1][lx], ct.w[py][1]));
+                v = __fadd_rn(v, __fmul_rn(hz[rr + 2][lx], ct.w[py][2]));
+                v = __fadd_rn(v, __fmul_rn(hz[rr + 3][lx], ct.w[py][3]));
+                if (v < 0.1f) v = 0.f;
+            }
+            tile[ly][lx] = v;
+        }
     }
     __syncthreads();
-    const int ly = tid / PT + 1, lx = tid % PT + 1;
-    const int Y = ty0 + ly - 1, X = tx0 + lx - 1;
-    if (Y < Hf && X < Wf) {
-        const float c = tile[ly][lx];
-        if (c > tile[ly][lx + 1] && c > tile[ly][lx - 1] && c > tile[ly + 1][lx] && c > tile[ly - 1][lx]) {
-            const int slot = n * gridDim.y + t;
-            const int pos = atomicAdd(&ws.peak_count[slot], 1);
-            if (pos < ws.caps.max_peaks) {
-                ws.peak_key[(int64_t)slot * ws.caps.max_peaks + pos] = ((uint32_t)X << 16) | (uint32_t)Y;
-                ws.peak_val[(int64_t)slot * ws.caps.max_peaks + pos] = c;
+    for (int i = tid; i < PTH * PTW; i += 256) {
+        const int ly = i / PTW + 1, lx = i % PTW + 1;
+        const int Y = Y0 + ly - 1, X = X0 + lx - 1;
+        if (Y < Hf && X < Wf) {
+            const float c = tile[ly][lx];
+            if (c > tile[ly][lx + 1] && c > tile[ly][lx - 1] && c > tile[ly + 1][lx] && c > tile[ly - 1][lx]) {
+                const int slot = n * gridDim.y + t;
+                const int pos = atomicAdd(&ws.peak_count[slot], 1);
+                if (pos < ws.caps.max_peaks) {
+                    ws.peak_key[(int64_t)slot * ws.caps.max_peaks + pos] = ((uint32_t)X << 16) | (uint32_t)Y;
+                    ws.peak_val[(int64_t)slot * ws.caps.max_peaks + pos] = c;
+                }
             }
         }
     }
 }
 hipError_t launch_find_peaks(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s) {
     const int Hf = heat.h * ratio, Wf = heat.w * ratio;
-    const int tiles = ((Wf + PT - 1) / PT) * ((Hf + PT - 1) / PT);
-    hipLaunchKernelGGL(find_peaks_kernel, dim3(tiles, ntypes, N), dim3(PT * PT), 0, s, heat, ratio, ws);
+    const int tiles = ((Wf + PTW - 1) / PTW) * ((Hf + PTH - 1) / PTH);
+    const dim3 grid(tiles, ntypes, N);
+    if (ratio == 1) hipLaunchKernelGGL(find_peaks_kernel<1>, grid, dim3(256), 0, s, heat, ws);
+    else if (ratio == 4) hipLaunchKernelGGL(find_peaks_kernel<4>, grid, dim3(256), 0, s, heat, ws);
+    else hipLaunchKernelGGL(find_peaks_kernel<8>, grid, dim3(256), 0, s, heat, ws);
     return hipGetLastError();
 }
 
@@ -259,7 +314,10 @@ __constant__ int c_limb_paf[19][2] = {{12, 13}, {20, 21}, {14, 15}, {16, 17}, {2
                                       {8, 9}, {10, 11}, {28, 29}, {30, 31}, {34, 35}, {32, 33}, {36, 37}, {18, 19}, {26, 27}};
 
 // keypoints.py:95-139 for one (frame, limb): every (i, j) candidate pair, float64 like NumPy.
-constexpr int SP_BLOCKS = 8;
+// 16 lanes per pair: sub-lanes 0..9 evaluate the 10 line-integral samples, sub-lane 10 the mid-point test, in
+// parallel (each is two bicubic PAF samples = 32 gathers); sub-lane 0 then adds the passed samples in k order,
+// exactly the reference's sequential sum.
+constexpr int SP_BLOCKS = 16;
 __global__ void __launch_bounds__(256) score_pairs_kernel(MapView paf, int ratio, int demo, PostWorkspace ws) {
     const int limb = blockIdx.y, n = blockIdx.z;
     const int ta = c_limb_kpt[limb][0], tb = c_limb_kpt[limb][1];
@@ -273,44 +331,59 @@ __global__ void __launch_bounds__(256) score_pairs_kernel(MapView paf, int ratio
     const int* xa = ws.kpt_xy + (int64_t)(n * 18 + ta) * kcap * 2;
     const int* xb = ws.kpt_xy + (int64_t)(n * 18 + tb) * kcap * 2;
     unsigned long long* fl = ws.flags + n * 4;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < npairs; p += SP_BLOCKS * 256) {
-        const int i = p / nb, j = p - i * nb;
+    const int sub = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63;
+    const int grp0 = lane & ~15;                                   // first lane of this 16-lane group
+    const int npair_iters = (npairs + SP_BLOCKS * 16 - 1) / (SP_BLOCKS * 16);
+    for (int itp = 0; itp < npair_iters; ++itp) {                  // uniform trip count: shuffles need all lanes
+        const int p = (itp * SP_BLOCKS + blockIdx.x) * 16 + (threadIdx.x >> 4);
+        const bool valid = p < npairs;
+        const int pp = valid ? p : 0;
+        const int i = pp / nb, j = pp - i * nb;
         const int ax = xa[i * 2], ay = xa[i * 2 + 1], bx = xb[j * 2], by = xb[j * 2 + 1];
         const int dx = bx - ax, dy = by - ay;
         const double norm = sqrt((double)((long long)dx * dx + (long long)dy * dy));
-        if (norm == 0.0) continue;
+        const bool live = valid && norm != 0.0;
         const double ux = (double)dx / norm, uy = (double)dy / norm;
-        const unsigned long long order = ((unsigned long long)limb << 32) | (unsigned)p;
-        // mid-point test (keypoints.py:99-116): only its sign vs -100 matters
-        const int mx = (int)rint(__dmul_rn((double)(ax + bx), 0.5)), my = (int)rint(__dmul_rn((double)(ay + by), 0.5));
-        const double mid = __dadd_rn(__dmul_rn(ux, (double)sample_map(paf, n, c0, my, mx, ratio)),
-                                     __dmul_rn(uy, (double)sample_map(paf, n, c1, my, mx, ratio)));
-        if (!(mid > -100.0)) {
-            atomicMin(&fl[1], order);
-            continue;
+        int px, py;
+        if (sub < 10) {
+            const double x = __dadd_rn(__dmul_rn(__dmul_rn(1.0 / 9.0, (double)dx), (double)sub), (double)ax);
+            const double y = __dadd_rn(__dmul_rn(__dmul_rn(1.0 / 9.0, (double)dy), (double)sub), (double)ay);
+            px = demo ? (int)x : (int)rint(x);
+            py = demo ? (int)y : (int)rint(y);
+        } else {                                                   // mid-point (keypoints.py:99-102)
+            px = (int)rint(__dmul_rn((double)(ax + bx), 0.5));
+            py = (int)rint(__dmul_rn((double)(ay + by), 0.5));
         }
-        atomicMin(&fl[2], order);
-        const double sx = __dmul_rn(1.0 / 9.0, (double)dx), sy = __dmul_rn(1.0 / 9.0, (double)dy);
+        double sc = 0.0;
+        if (live && sub <= 10)
+            sc = __dadd_rn(__dmul_rn(ux, (double)sample_map(paf, n, c0, py, px, ratio)),
+                           __dmul_rn(uy, (double)sample_map(paf, n, c1, py, px, ratio)));
+        const double mid = __shfl(sc, grp0 + 10);
         double acc = 0.0;
         int cnt = 0;
+#pragma unroll
         for (int k = 0; k < 10; ++k) {
-            const double x = __dadd_rn(__dmul_rn(sx, (double)k), (double)ax);
-            const double y = __dadd_rn(__dmul_rn(sy, (double)k), (double)ay);
-            const int px = demo ? (int)x : (int)rint(x);
-            const int py = demo ? (int)y : (int)rint(y);
-            const double s = __dadd_rn(__dmul_rn(ux, (double)sample_map(paf, n, c0, py, px, ratio)),
-                                       __dmul_rn(uy, (double)sample_map(paf, n, c1, py, px, ratio)));
+            const double s = __shfl(sc, grp0 + k);
             if (s > 0.05) { acc = __dadd_rn(acc, s); ++cnt; }
         }
-        double rat = cnt > 0 ? acc / (double)cnt : 0.0;
-        const double pen = __dadd_rn(height_n / norm, -1.0);
-        rat = __dadd_rn(rat, pen < 0.0 ? pen : 0.0);
-        if (rat > 0.0 && cnt >= 9) {
-            const int slot = n * 19 + limb;
-            const int pos = atomicAdd(&ws.conn_count[slot], 1);
-            if (pos < ws.caps.max_conn) {
-                ws.conn_ij[(int64_t)slot * ws.caps.max_conn + pos] = (i << 16) | j;
-                ws.conn_ratio[(int64_t)slot * ws.caps.max_conn + pos] = rat;
+        if (live && sub == 0) {
+            const unsigned long long order = ((unsigned long long)limb << 32) | (unsigned)p;
+            if (!(mid > -100.0)) {
+                atomicMin(&fl[1], order);
+            } else {
+                atomicMin(&fl[2], order);
+                double rat = cnt > 0 ? acc / (double)cnt : 0.0;
+                const double pen = __dadd_rn(height_n / norm, -1.0);
+                rat = __dadd_rn(rat, pen < 0.0 ? pen : 0.0);
+                if (rat > 0.0 && cnt >= 9) {
+                    const int slot = n * 19 + limb;
+                    const int pos = atomicAdd(&ws.conn_count[slot], 1);
+                    if (pos < ws.caps.max_conn) {
+                        ws.conn_ij[(int64_t)slot * ws.caps.max_conn + pos] = (i << 16) | j;
+                        ws.conn_ratio[(int64_t)slot * ws.caps.max_conn + pos] = rat;
+                    }
+                }
             }
         }
     }
@@ -320,176 +393,337 @@ hipError_t launch_score_pairs(const MapView& paf, int N, int ratio, int demo, Po
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------ assembly
-// keypoints.py:63-92 (one-sided limbs), 140-155 (stable sort by ratio + greedy 1-1 matching),
-// 159-193 (pose assembly), 195-199 (filter).  One wavefront per frame; pose entries live in LDS.
+// ------------------------------------------------------------------------------------------------ matching
+// keypoints.py:140-155 per (frame, limb), all limbs in parallel: stable sort by descending ratio + greedy 1-1
+// matching == repeatedly take the best candidate whose two end points are still free.  One wavefront per limb;
+// candidates staged in LDS (global fallback beyond MATCH_LDS).  Output: the selected connections in pick order.
+constexpr int MATCH_LDS = 1024;
 __device__ __forceinline__ bool better(double ra, int ija, double rb, int ijb) {
     return ra > rb || (ra == rb && ija < ijb);     // descending ratio, ties in (i, j) order = stable sort
 }
-
-__global__ void __launch_bounds__(64) assemble_kernel(PostWorkspace ws) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char asm_smem[];
-    const int n = blockIdx.x, lane = threadIdx.x;
-    const int kcap = ws.caps.max_kpts, ecap = ws.caps.max_entries, ccap = ws.caps.max_conn;
-    double* ent = (double*)asm_smem;                         // [ecap][20]
-    double* sel_r = ent + (size_t)ecap * 20;                  // [kcap]
-    int* sel_a = (int*)(sel_r + kcap);                        // [kcap] global ids
-    int* sel_b = sel_a + kcap;                                // [kcap]
-    int* used_a = sel_b + kcap;                               // [kcap]
-    int* used_b = used_a + kcap;                              // [kcap]
-    int* off = used_b + kcap;                                 // [19]
-    unsigned long long* fl = ws.flags + n * 4;
-
-    if (lane == 0) {
-        int o = 0;
-        for (int t = 0; t < 18; ++t) { off[t] = o; o += ws.kpt_count[n * 18 + t]; }
-        off[18] = o;
+__global__ void __launch_bounds__(64) match_kernel(PostWorkspace ws) {
+    __shared__ double s_r[MATCH_LDS];
+    __shared__ int s_ij[MATCH_LDS];
+    extern __shared__ __attribute__((aligned(16))) int used[];     // [2 * kcap]
+    const int limb = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+    const int slot = n * 19 + limb;
+    const int kcap = ws.caps.max_kpts, ccap = ws.caps.max_conn;
+    const int ta = c_limb_kpt[limb][0], tb = c_limb_kpt[limb][1];
+    const int na = ws.kpt_count[n * 18 + ta], nb = ws.kpt_count[n * 18 + tb];
+    int m = ws.conn_count[slot];
+    if (m > ccap) {
+        if (lane == 0) atomicOr(&ws.flags[n * 4 + 0], 4ull);
+        m = ccap;
     }
-    __syncthreads();
-    // all_keypoints (K, 4) float64: x, y, score, id   (keypoints.py:53)
-    double* ko = ws.kpts_out + (int64_t)n * 18 * kcap * 4;
-    for (int t = 0; t < 18; ++t) {
-        const int c = ws.kpt_count[n * 18 + t];
-        for (int i = lane; i < c; i += 64) {
+    const int* cij = ws.conn_ij + (int64_t)slot * ccap;
+    const double* crat = ws.conn_ratio + (int64_t)slot * ccap;
+    if (limb < 18) {   // this wave also writes type `limb`'s rows of all_keypoints (K,4) f64: x, y, score, id (keypoints.py:53)
+        const int t = limb;
+        const int c_t = ws.kpt_count[n * 18 + t];
+        int below = (lane < t) ? ws.kpt_count[n * 18 + lane] : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) below += __shfl_xor(below, d);
+        double* ko = ws.kpts_out + (int64_t)n * 18 * kcap * 4;
+        for (int i = lane; i < c_t; i += 64) {
             const int64_t src = (int64_t)(n * 18 + t) * kcap + i;
-            double* row = ko + (int64_t)(off[t] + i) * 4;
+            double* row = ko + (int64_t)(below + i) * 4;
             row[0] = (double)ws.kpt_xy[src * 2];
             row[1] = (double)ws.kpt_xy[src * 2 + 1];
             row[2] = (double)ws.kpt_score[src];
-            row[3] = (double)(off[t] + i);
+            row[3] = (double)(below + i);
         }
     }
-    int n_ent = 0;
-    bool overflow = false;
-    auto kscore = [&](int t, int i) { return (double)ws.kpt_score[(int64_t)(n * 18 + t) * kcap + i]; };
-    auto append = [&](int slot_a, double ida, int slot_b, double idb, double cnt, double score) {
-        if (n_ent >= ecap) { overflow = true; return; }
-        if (lane < 20) {
-            double v = -1.0;
-            if (lane == slot_a) v = ida;
-            if (lane == slot_b) v = idb;
-            if (lane == 19) v = cnt;
-            if (lane == 18) v = score;
-            ent[(size_t)n_ent * 20 + lane] = v;
+    const bool in_lds = m <= MATCH_LDS;
+    if (in_lds)
+        for (int q = lane; q < m; q += 64) { s_ij[q] = cij[q]; s_r[q] = crat[q]; }
+    for (int i = lane; i < 2 * kcap; i += 64) used[i] = 0;
+    __syncthreads();
+    const int want = na < nb ? na : nb;
+    int nsel = 0;
+    int* sel_ij = ws.sel_ij + (int64_t)slot * kcap;
+    double* sel_r = ws.sel_r + (int64_t)slot * kcap;
+    while (nsel < want && m > 0) {
+        double br = -1.0; int bij = 0x7FFFFFFF;
+        for (int q = lane; q < m; q += 64) {
+            const int ij = in_lds ? s_ij[q] : cij[q];
+            if (used[ij >> 16] || used[kcap + (ij & 0xFFFF)]) continue;
+            const double r = in_lds ? s_r[q] : crat[q];
+            if (better(r, ij, br, bij)) { br = r; bij = ij; }
         }
-        ++n_ent;
-        __syncthreads();
-    };
-
-    for (int limb = 0; limb < 19; ++limb) {
-        const int ta = c_limb_kpt[limb][0], tb = c_limb_kpt[limb][1];
-        const int na = ws.kpt_count[n * 18 + ta], nb = ws.kpt_count[n * 18 + tb];
-        if (na == 0 && nb == 0) continue;
-        if (na == 0 || nb == 0) {
-            const int t = na == 0 ? tb : ta, c = na == 0 ? nb : na;
-            for (int i = 0; i < c; ++i) {
-                const double id = (double)(off[t] + i);
-                bool found = false;
-                for (int e = lane; e < n_ent; e += 64) found |= ent[(size_t)e * 20 + t] == id;
-                if (!__any(found)) append(t, id, -1, 0.0, 1.0, kscore(t, i));
-            }
-            continue;
-        }
-        // greedy 1-1 matching in stable descending-ratio order == repeatedly take the best candidate
-        // whose two end points are still free
-        int m = ws.conn_count[n * 19 + limb];
-        if (m > ccap) { overflow = true; m = ccap; }
-        const int* cij = ws.conn_ij + (int64_t)(n * 19 + limb) * ccap;
-        const double* crat = ws.conn_ratio + (int64_t)(n * 19 + limb) * ccap;
-        for (int i = lane; i < kcap; i += 64) { used_a[i] = 0; used_b[i] = 0; }
-        __syncthreads();
-        const int want = na < nb ? na : nb;
-        int nsel = 0;
-        while (nsel < want) {
-            double br = -1.0; int bij = 0x7FFFFFFF;
-            for (int q = lane; q < m; q += 64) {
-                const int ij = cij[q];
-                if (used_a[ij >> 16] || used_b[ij & 0xFFFF]) continue;
-                const double r = crat[q];
-                if (better(r, ij, br, bij)) { br = r; bij = ij; }
-            }
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                const double orr = __shfl_xor(br, d);
-                const int oij = __shfl_xor(bij, d);
-                if (better(orr, oij, br, bij)) { br = orr; bij = oij; }
-            }
-            if (bij == 0x7FFFFFFF) break;
-            if (lane == 0) {
-                used_a[bij >> 16] = 1; used_b[bij & 0xFFFF] = 1;
-                sel_a[nsel] = off[ta] + (bij >> 16);
-                sel_b[nsel] = off[tb] + (bij & 0xFFFF);
-                sel_r[nsel] = br;
-            }
-            ++nsel;
-            __syncthreads();
+        for (int d = 32; d > 0; d >>= 1) {
+            const double orr = __shfl_xor(br, d);
+            const int oij = __shfl_xor(bij, d);
+            if (better(orr, oij, br, bij)) { br = orr; bij = oij; }
         }
-        if (nsel == 0) continue;
-        if (limb == 0) {
-            n_ent = 0;
-            for (int q = 0; q < nsel; ++q) {
-                const int ia = sel_a[q], ib = sel_b[q];
-                const double sc = __dadd_rn(__dadd_rn(kscore(ta, ia - off[ta]), kscore(tb, ib - off[tb])), sel_r[q]);
-                append(ta, (double)ia, tb, (double)ib, 2.0, sc);
+        if (bij == 0x7FFFFFFF) break;
+        if (lane == 0) {
+            used[bij >> 16] = 1; used[kcap + (bij & 0xFFFF)] = 1;
+            sel_ij[nsel] = bij; sel_r[nsel] = br;
+        }
+        ++nsel;
+        __syncthreads();
+    }
+    // scores of the two end points, gathered here (all limbs in parallel) so the sequential assembly needs no gathers
+    for (int q = lane; q < nsel; q += 64) {
+        const int ij = sel_ij[q];
+        ws.sel_sa[(int64_t)slot * kcap + q] = ws.kpt_score[(int64_t)(n * 18 + ta) * kcap + (ij >> 16)];
+        ws.sel_sb[(int64_t)slot * kcap + q] = ws.kpt_score[(int64_t)(n * 18 + tb) * kcap + (ij & 0xFFFF)];
+    }
+    if (lane == 0) ws.sel_count[slot] = nsel;
+}
+hipError_t launch_match(int N, PostWorkspace& ws, hipStream_t s) {
+    hipLaunchKernelGGL(match_kernel, dim3(19, N), dim3(64), (size_t)ws.caps.max_kpts * 2 * sizeof(int), s, ws);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ assembly
+// keypoints.py:63-92 (one-sided limbs), 159-193 (pose assembly), 195-199 (filter).  Inherently sequential over
+// limbs and connections: one wavefront per frame, lanes = pose entries.  Entries live in LDS (global scratch
+// when max_entries is too large for LDS).  Everything the sequential part reads — the connections picked by
+// match_kernel with their scores (first ASM_STAGE per limb) and the key-point scores (first ASM_STAGE per type) —
+// is staged into LDS by one round of independent loads, so no global-memory latency sits on the serial chain.
+// Cost model (measured with s_memtime stamps): this kernel is ONE wavefront, so every dependent LDS round trip
+// (ds_read, ds_bpermute/__shfl) costs ~120-150 cycles and nothing hides it.  The serial part therefore lives in
+// registers and SGPRs only:
+//   * pose entries 0..63: lane e owns entry e (18 int key-point ids, f64 score, int count); entries >= 64 spill
+//     to `ext` rows in LDS / global scratch (rare: > 64 partial poses in one frame);
+//   * the connections picked by match_kernel: lane q owns connection q of every limb (loaded once, up front);
+//   * matching = a wave-uniform loop over the limb's connections: v_readlane broadcast + integer compare + ballot.
+// The loop follows the reference's order exactly (keypoints.py:159-193): limbs in order, connections in pick order,
+// every matching entry updated, a new entry appended when none matched.
+template <int L> struct LimbT {
+    static constexpr int kA[19] = {1, 1, 2, 3, 5, 6, 1, 8, 9, 1, 11, 12, 1, 0, 14, 0, 15, 2, 5};
+    static constexpr int kB[19] = {2, 5, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 14, 16, 15, 17, 16, 17};
+    static constexpr int ta = kA[L], tb = kB[L];
+};
+struct AsmConn {           // lane q: connection q of limb l (q < 64), and key-point q's score per type
+    int ij[19];
+    double r[19];
+    float sa[19], sb[19];
+    float sc[18];
+    int my_off;            // lane t < 19: first all_keypoints row of type t (lane 18: total)
+    int my_nsel;           // lane l < 19: number of connections of limb l
+};
+struct AsmCtx {
+    int id[18];
+    double score;
+    int count;
+    int n_ent;             // uniform
+    bool overflow;
+    double* ext;           // [ecap - 64][20]
+    int ecap, lane;
+};
+__device__ __forceinline__ double readlane_f64(double v, int l) {     // l must be wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <int TA, int TB>
+__device__ __forceinline__ void asm_append(AsmCtx& c, int ida, int idb, int cnt, double score) {   // uniform arguments
+    if (c.n_ent >= c.ecap) { c.overflow = true; return; }
+    if (c.n_ent < 64) {
+        if (c.lane == c.n_ent) {
+#pragma unroll
+            for (int k = 0; k < 18; ++k) c.id[k] = (k == TA) ? ida : ((k == TB) ? idb : -1);
+            c.score = score;
+            c.count = cnt;
+        }
+    } else {
+        if (c.lane < 20) {
+            double v = -1.0;
+            if (c.lane == TA) v = (double)ida;
+            if (c.lane == TB) v = (double)idb;
+            if (c.lane == 19) v = (double)cnt;
+            if (c.lane == 18) v = score;
+            c.ext[(size_t)(c.n_ent - 64) * 20 + c.lane] = v;
+        }
+        __syncthreads();
+    }
+    ++c.n_ent;
+}
+
+template <int L, bool EXT_LDS>
+__device__ __forceinline__ void asm_limb(AsmCtx& c, const AsmConn& cn, const PostWorkspace& ws, int n) {
+    constexpr int ta = LimbT<L>::ta, tb = LimbT<L>::tb;
+    const int kcap = ws.caps.max_kpts;
+    const int lane = c.lane;
+    const int offa = __builtin_amdgcn_readlane(cn.my_off, ta), offb = __builtin_amdgcn_readlane(cn.my_off, tb);
+    const int na = __builtin_amdgcn_readlane(cn.my_off, ta + 1) - offa, nb = __builtin_amdgcn_readlane(cn.my_off, tb + 1) - offb;
+    if (na == 0 && nb == 0) return;
+    const bool spilled = c.n_ent > 64;
+    if (na == 0 || nb == 0) {                       // one-sided limb (keypoints.py:65-92)
+        constexpr int dummy = 0; (void)dummy;
+        const int cnt = na == 0 ? nb : na;
+        for (int i = 0; i < cnt; ++i) {
+            bool found;
+            if (na == 0) {
+                const int id = offb + i;
+                found = lane < c.n_ent && lane < 64 && c.id[tb] == id;
+                if (spilled) for (int x = 64 + lane; x < c.n_ent; x += 64) found |= c.ext[(size_t)(x - 64) * 20 + tb] == (double)id;
+                if (!__any(found)) {
+                    const double sc = i < 64 ? (double)readlane_f32(cn.sc[tb], i) : (double)ws.kpt_score[(int64_t)(n * 18 + tb) * kcap + i];
+                    asm_append<tb, -1>(c, id, 0, 1, sc);
+                }
+            } else {
+                const int id = offa + i;
+                found = lane < c.n_ent && lane < 64 && c.id[ta] == id;
+                if (spilled) for (int x = 64 + lane; x < c.n_ent; x += 64) found |= c.ext[(size_t)(x - 64) * 20 + ta] == (double)id;
+                if (!__any(found)) {
+                    const double sc = i < 64 ? (double)readlane_f32(cn.sc[ta], i) : (double)ws.kpt_score[(int64_t)(n * 18 + ta) * kcap + i];
+                    asm_append<ta, -1>(c, id, 0, 1, sc);
+                }
             }
-        } else if (limb == 17 || limb == 18) {
-            for (int q = 0; q < nsel; ++q) {
-                const double ia = (double)sel_a[q], ib = (double)sel_b[q];
-                for (int e = lane; e < n_ent; e += 64) {
-                    double* en = ent + (size_t)e * 20;
-                    if (en[ta] == ia && en[tb] == -1.0) en[tb] = ib;
-                    else if (en[tb] == ib && en[ta] == -1.0) en[ta] = ia;
+        }
+        return;
+    }
+    const int nsel = __builtin_amdgcn_readlane(cn.my_nsel, L);
+    if (nsel == 0) return;
+    const int64_t gsel = (int64_t)(n * 19 + L) * kcap;
+    if (L == 0) c.n_ent = 0;                        // keypoints.py:159-165
+    for (int q = 0; q < nsel; ++q) {
+        int ij; double r; float sa, sb;
+        if (q < 64) {
+            ij = __builtin_amdgcn_readlane(cn.ij[L], q);
+            r = readlane_f64(cn.r[L], q); sa = readlane_f32(cn.sa[L], q); sb = readlane_f32(cn.sb[L], q);
+        } else { ij = ws.sel_ij[gsel + q]; r = ws.sel_r[gsel + q]; sa = ws.sel_sa[gsel + q]; sb = ws.sel_sb[gsel + q]; }
+        const int ia = offa + (ij >> 16), ib = offb + (ij & 0xFFFF);
+        const bool mine = lane < c.n_ent && lane < 64;
+        if (L == 0) {
+            asm_append<ta, tb>(c, ia, ib, 2, __dadd_rn(__dadd_rn((double)sa, (double)sb), r));
+        } else if (L == 17 || L == 18) {            // keypoints.py:166-175: only fill a missing end point
+            if (mine) {
+                if (c.id[ta] == ia && c.id[tb] == -1) c.id[tb] = ib;
+                else if (c.id[tb] == ib && c.id[ta] == -1) c.id[ta] = ia;
+            }
+            if (spilled) {
+                const double iad = (double)ia, ibd = (double)ib;
+                for (int x = 64 + lane; x < c.n_ent; x += 64) {
+                    double* en = c.ext + (size_t)(x - 64) * 20;
+                    if (en[ta] == iad && en[tb] == -1.0) en[tb] = ibd;
+                    else if (en[tb] == ibd && en[ta] == -1.0) en[ta] = iad;
                 }
                 __syncthreads();
             }
-        } else {
-            for (int q = 0; q < nsel; ++q) {
-                const int ib_i = sel_b[q];
-                const double ia = (double)sel_a[q], ib = (double)ib_i, r = sel_r[q];
-                const double add = __dadd_rn(kscore(tb, ib_i - off[tb]), r);
-                bool hit = false;
-                for (int e = lane; e < n_ent; e += 64) {
-                    double* en = ent + (size_t)e * 20;
-                    if (en[ta] == ia) {
-                        en[tb] = ib;
+        } else {                                    // keypoints.py:176-186
+            const bool match = mine && c.id[ta] == ia;
+            bool hit = __any(match);
+            if (match) {
+                c.id[tb] = ib;
+                c.count += 1;
+                c.score = __dadd_rn(c.score, __dadd_rn((double)sb, r));
+            }
+            if (spilled) {
+                const double iad = (double)ia, ibd = (double)ib, add = __dadd_rn((double)sb, r);
+                bool h2 = false;
+                for (int x = 64 + lane; x < c.n_ent; x += 64) {
+                    double* en = c.ext + (size_t)(x - 64) * 20;
+                    if (en[ta] == iad) {
+                        en[tb] = ibd;
                         en[19] = __dadd_rn(en[19], 1.0);
                         en[18] = __dadd_rn(en[18], add);
-                        hit = true;
+                        h2 = true;
                     }
                 }
                 __syncthreads();
-                if (!__any(hit)) {
-                    const double sc = __dadd_rn(__dadd_rn(kscore(ta, sel_a[q] - off[ta]), kscore(tb, ib_i - off[tb])), r);
-                    append(ta, ia, tb, ib, 2.0, sc);
-                }
+                hit |= __any(h2);
             }
+            if (!hit) asm_append<ta, tb>(c, ia, ib, 2, __dadd_rn(__dadd_rn((double)sa, (double)sb), r));   // keypoints.py:187-193
         }
     }
+}
+
+template <bool EXT_LDS>
+__global__ void __launch_bounds__(64) assemble_kernel(PostWorkspace ws) {
+    extern __shared__ __attribute__((aligned(16))) double asm_ext[];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const int kcap = ws.caps.max_kpts, ecap = ws.caps.max_entries;
+#ifdef LWP_ASM_STAMPS
+    unsigned long long stamps[4];
+#define STAMP(i) do { stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+    STAMP(0);
+    AsmConn cn;
+    {   // one round of independent, unconditional loads (index clamped, never branched)
+        const int li = lane < kcap ? lane : kcap - 1;
+        const int my_cnt = lane < 18 ? ws.kpt_count[n * 18 + lane] : 0;
+        cn.my_nsel = lane < 19 ? ws.sel_count[n * 19 + lane] : 0;
+#pragma unroll
+        for (int l = 0; l < 19; ++l) {
+            const int64_t src = (int64_t)(n * 19 + l) * kcap + li;
+            cn.ij[l] = ws.sel_ij[src]; cn.r[l] = ws.sel_r[src]; cn.sa[l] = ws.sel_sa[src]; cn.sb[l] = ws.sel_sb[src];
+        }
+#pragma unroll
+        for (int t = 0; t < 18; ++t) cn.sc[t] = ws.kpt_score[(int64_t)(n * 18 + t) * kcap + li];
+        int incl = my_cnt;                           // inclusive prefix over lanes (DPP row shifts, no LDS)
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        cn.my_off = incl - my_cnt;                   // lane 18 holds the total (its own count is 0)
+    }
+    STAMP(1);
+    AsmCtx c;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) c.id[k] = -1;
+    c.score = 0.0; c.count = 0;
+    c.n_ent = 0; c.overflow = false; c.ecap = ecap; c.lane = lane;
+    c.ext = EXT_LDS ? asm_ext : ws.entries_work + (int64_t)n * ecap * 20;
+#define LWP_LIMB(L) asm_limb<L, EXT_LDS>(c, cn, ws, n);
+    LWP_LIMB(0) LWP_LIMB(1) LWP_LIMB(2) LWP_LIMB(3) LWP_LIMB(4) LWP_LIMB(5) LWP_LIMB(6) LWP_LIMB(7) LWP_LIMB(8) LWP_LIMB(9)
+    LWP_LIMB(10) LWP_LIMB(11) LWP_LIMB(12) LWP_LIMB(13) LWP_LIMB(14) LWP_LIMB(15) LWP_LIMB(16) LWP_LIMB(17) LWP_LIMB(18)
+#undef LWP_LIMB
+    STAMP(2);
     // filter (keypoints.py:195-199), order preserved
     double* out = ws.entries + (int64_t)n * ecap * 20;
     int kept = 0;
-    for (int e0 = 0; e0 < n_ent; e0 += 64) {
+    {
+        const double cntd = (double)c.count;
+        const bool keep = lane < c.n_ent && !(cntd < 3.0 || c.score / cntd < 0.2);
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+#pragma unroll
+            for (int k = 0; k < 18; ++k) out[(int64_t)pos * 20 + k] = (double)c.id[k];
+            out[(int64_t)pos * 20 + 18] = c.score;
+            out[(int64_t)pos * 20 + 19] = cntd;
+        }
+        kept = __popcll(mask);
+    }
+    for (int e0 = 64; e0 < c.n_ent; e0 += 64) {
         const int e = e0 + lane;
         bool keep = false;
-        if (e < n_ent) {
-            const double c = ent[(size_t)e * 20 + 19], s = ent[(size_t)e * 20 + 18];
-            keep = !(c < 3.0 || s / c < 0.2);
-        }
+        const double* en = c.ext + (size_t)(e - 64) * 20;
+        if (e < c.n_ent) keep = !(en[19] < 3.0 || en[18] / en[19] < 0.2);
         const unsigned long long mask = __ballot(keep);
         if (keep) {
             const int pos = kept + __popcll(mask & ((1ull << lane) - 1ull));
-            for (int k = 0; k < 20; ++k) out[(int64_t)pos * 20 + k] = ent[(size_t)e * 20 + k];
+            for (int k = 0; k < 20; ++k) out[(int64_t)pos * 20 + k] = en[k];
         }
         kept += __popcll(mask);
     }
     if (lane == 0) {
         ws.n_entries[n] = kept;
-        if (overflow) atomicOr(&fl[0], 4ull);
+        if (c.overflow) atomicOr(&ws.flags[n * 4 + 0], 4ull);
     }
+    // leave the atomic append counters zeroed for the next pass (the fused pipeline has no separate reset launch)
+    if (lane < 18) ws.peak_count[n * 18 + lane] = 0;
+    if (lane < 19) ws.conn_count[n * 19 + lane] = 0;
+    STAMP(3);
+#ifdef LWP_ASM_STAMPS
+    if (lane == 0) printf("assemble frame %d: stage %llu limbs %llu filter %llu cycles, n_ent %d\n", n, stamps[1] - stamps[0],
+                          stamps[2] - stamps[1], stamps[3] - stamps[2], c.n_ent);
+#endif
 }
 hipError_t launch_assemble(int N, PostWorkspace& ws, hipStream_t s) {
-    const size_t lds = (size_t)ws.caps.max_entries * 20 * 8 + (size_t)ws.caps.max_kpts * (8 + 4 * 4) + 20 * 4 + 16;
-    hipLaunchKernelGGL(assemble_kernel, dim3(N), dim3(64), lds, s, ws);
+    const size_t ext_bytes = ws.caps.max_entries > 64 ? (size_t)(ws.caps.max_entries - 64) * 20 * 8 : 16;
+    if (ext_bytes <= 60 * 1024) hipLaunchKernelGGL(assemble_kernel<true>, dim3(N), dim3(64), ext_bytes, s, ws);
+    else hipLaunchKernelGGL(assemble_kernel<false>, dim3(N), dim3(64), 16, s, ws);
     return hipGetLastError();
 }
 

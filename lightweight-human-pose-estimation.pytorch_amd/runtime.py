@@ -224,6 +224,11 @@ class Engine(object):
         self._last_N = N
         return ms.value
 
+    def time_layer(self, layer_index, N, H, W, iters=50):
+        ms = C.c_float()
+        check(lib().lwp_debug_time_layer(self.h.ptr, layer_index, N, H, W, iters, C.byref(ms)), self.h.ptr)
+        return ms.value
+
     def profile_launches(self, x_cuda, reps=5, upsample_ratio=4, demo=True):
         """[(name, class, ms)] per launch in issue order (HIP events around every launch)."""
         N, _, H, W = x_cuda.shape
@@ -233,7 +238,7 @@ class Engine(object):
         n = C.c_int()
         check(lib().lwp_profile_launches(self.h.ptr, x_cuda.data_ptr(), N, H, W, upsample_ratio, 1 if demo else 0, reps, ms, kc, cap, C.byref(n)), self.h.ptr)
         layers = self.layers()
-        post = ["reset_ws", "find_peaks", "nms", "score_pairs", "assemble"]
+        post = ["find_peaks", "nms", "score_pairs", "match", "assemble"]
         names = [l["name"] for l in layers] + post
         return [(names[i] if i < len(names) else "launch%d" % i, kc[i], ms[i]) for i in range(n.value)]
 

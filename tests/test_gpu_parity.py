@@ -288,7 +288,7 @@ def test_noise_saturated_maps_with_raised_capacity():
     x = net_input(1, 368, 656, seed=0)
     with pytest.raises(CapacityError):
         net.engine.infer_poses(x, 4, demo=True)
-    net.engine.set_capacity(8192, 1024, 1 << 20, 640)
+    net.engine.set_capacity(8192, 1024, 1 << 20, 4096)   # entries beyond LDS: global-scratch path
     e, a, c = net.engine.infer_poses(x, 4, demo=True)[0]
     outs = net(x)
     hu = post_ref.upsample_cubic(outs[-2][0].transpose(1, 2, 0), 4)
