@@ -41,6 +41,10 @@ def layer_work(layers, N, H, W, elt_bytes=4):
             k = "stem"
             flops = 2.0 * m_out * 27 * 32
             byt = (N * hi * wi * 3 + m_out * 32) * 4 + 27 * 32 * 4
+        elif l["kind"] == 3:       # fused depthwise -> pointwise: charged to the (MFMA-bound) 1x1 class with both ops' FLOPs
+            k = "pointwise_1x1"
+            flops = 2.0 * m_out * (9 * l["cin"] + l["cin"] * l["cout"])
+            byt = (N * hi * wi * l["cin"] + m_out * l["cout"] + 9 * l["cin"] + l["cin"] * l["cout"]) * elt_bytes
         elif l["kind"] == 1:
             k = "depthwise"
             flops = 2.0 * m_out * 9 * l["cin"]
@@ -152,7 +156,7 @@ def main():
         roofs = {}
         for k, (flops, byt) in work.items():
             ms, nl = classes[k]["ms"], max(classes[k]["launches"], 1)
-            if ms <= 0:
+            if ms <= 0 or flops <= 0:
                 continue
             if k in ("depthwise", "stem"):
                 ach = byt / (ms * 1e-3) / 1e9

@@ -2,6 +2,7 @@
 // launch sequence of the layer graph on the handle's HIP stream, result fetch, and event timing.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -109,7 +110,10 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
     lwp_context* h = new lwp_context();
     h->device = device_id;
     h->dtype = dtype;
-    h->g = build_graph(nref, C, NH, NP);
+    {
+        const char* fe = getenv("LWP_FUSE_DWPW");   // "0" keeps depthwise and pointwise as separate launches (A/B, tests)
+        h->g = build_graph(nref, C, NH, NP, !(fe && fe[0] == '0'));
+    }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     e = init_cubic_tables();
@@ -128,8 +132,9 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
 
 static void free_ws(lwp_context* h) {
     PostWorkspace& w = h->ws;
-    void* ptrs[] = {w.peak_count, w.peak_key, w.peak_val, w.kpt_count, w.kpt_xy, w.kpt_score, w.conn_count,
-                    w.conn_ij, w.conn_ratio, w.flags, w.entries, w.n_entries, w.kpts_out, w.sel_count, w.sel_ij, w.sel_r,
+    // flags / kpt_count / n_entries / kpts_out / entries live in ONE allocation (result_block) so the fetch is one copy
+    void* ptrs[] = {w.peak_count, w.peak_key, w.peak_val, w.kpt_xy, w.kpt_score, w.conn_count,
+                    w.conn_ij, w.conn_ratio, w.result_block, w.sel_count, w.sel_ij, w.sel_r,
                     w.entries_work, w.sel_sa, w.sel_sb};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = PostWorkspace();
@@ -240,22 +245,29 @@ static int ensure_ws(lwp_context* h, int N) {
     WS_ALLOC(peak_count, N * 18, int);
     WS_ALLOC(peak_key, (size_t)N * 18 * c.max_peaks, uint32_t);
     WS_ALLOC(peak_val, (size_t)N * 18 * c.max_peaks, float);
-    WS_ALLOC(kpt_count, N * 18, int);
     WS_ALLOC(kpt_xy, (size_t)N * 18 * c.max_kpts * 2, int);
     WS_ALLOC(kpt_score, (size_t)N * 18 * c.max_kpts, float);
     WS_ALLOC(conn_count, N * 19, int);
     WS_ALLOC(conn_ij, (size_t)N * 19 * c.max_conn, int);
     WS_ALLOC(conn_ratio, (size_t)N * 19 * c.max_conn, double);
-    WS_ALLOC(flags, (size_t)N * 4, unsigned long long);
-    WS_ALLOC(entries, (size_t)N * c.max_entries * 20, double);
+    {   // result block: [flags N*4 u64][kpts_out N*18*kcap*4 f64][entries N*ecap*20 f64][kpt_count N*18 i32][n_entries N i32]
+        const size_t b_fl = (size_t)N * 4 * 8, b_k = (size_t)N * 18 * c.max_kpts * 4 * 8, b_e = (size_t)N * c.max_entries * 20 * 8;
+        const size_t b_cnt = (size_t)N * 18 * 4, b_ne = (size_t)N * 4;
+        w.result_bytes = b_fl + b_k + b_e + b_cnt + b_ne;
+        HIP_TRY(h, hipMalloc((void**)&w.result_block, w.result_bytes));
+        char* q = (char*)w.result_block;
+        w.flags = (unsigned long long*)q; q += b_fl;
+        w.kpts_out = (double*)q; q += b_k;
+        w.entries = (double*)q; q += b_e;
+        w.kpt_count = (int*)q; q += b_cnt;
+        w.n_entries = (int*)q;
+    }
     WS_ALLOC(entries_work, (size_t)N * c.max_entries * 20, double);
     WS_ALLOC(sel_count, N * 19, int);
     WS_ALLOC(sel_ij, (size_t)N * 19 * c.max_kpts, int);
     WS_ALLOC(sel_r, (size_t)N * 19 * c.max_kpts, double);
     WS_ALLOC(sel_sa, (size_t)N * 19 * c.max_kpts, float);
     WS_ALLOC(sel_sb, (size_t)N * 19 * c.max_kpts, float);
-    WS_ALLOC(n_entries, N, int);
-    WS_ALLOC(kpts_out, (size_t)N * 18 * c.max_kpts * 4, double);
 #undef WS_ALLOC
     w.N = N;
     HIP_TRY(h, launch_reset_ws(N, w, h->stream));
@@ -312,6 +324,18 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
     if (l.kind == L_STEM) {
         StemParams p{d_in, wts, bias, dst, N, H, W, dh, dw};
         LAUNCH(h, KC_STEM, launch_stem(p, h->stream));
+    } else if (l.kind == L_DWPW) {
+        int sh, sw;
+        level_dims(H, W, g.bufs[l.src.buf].level, &sh, &sw);
+        DwPwParams p;
+        p.in = h->bufs[l.src.buf] + l.src.coff; p.in_ld = l.src.ld;
+        p.dw_w = wts; p.pw_w = h->d_blob + l.w2_off; p.pw_b = h->d_blob + l.b2_off;
+        p.out = dst; p.out_ld = l.dst.ld;
+        p.res = l.res.buf >= 0 ? h->bufs[l.res.buf] + l.res.coff : nullptr; p.res_ld = l.res.ld;
+        p.zeros = h->d_zeros;
+        p.N = N; p.Hi = sh; p.Wi = sw; p.Ho = dh; p.Wo = dw; p.C = l.cin; p.cout = l.cout;
+        p.stride = l.stride; p.dil = l.dil; p.act_dw = l.act; p.act_pw = l.act2;
+        LAUNCH(h, KC_PW, launch_dwpw(p, h->stream));
     } else if (l.kind == L_DW) {
         int sh, sw;
         level_dims(H, W, g.bufs[l.src.buf].level, &sh, &sw);
@@ -466,22 +490,17 @@ extern "C" int lwp_extract_keypoints(lwp_handle h, float* heatmap, int H, int W,
 // ---------------------------------------------------------------------------------------------- results
 static int fetch_results(lwp_context* h, int N, int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap, int* n_entries) {
     const PostCaps& c = h->ws.caps;
-    const size_t b_cnt = (size_t)N * 18 * sizeof(int), b_ne = (size_t)N * sizeof(int), b_fl = (size_t)N * 4 * 8;
-    const size_t b_k = (size_t)N * 18 * c.max_kpts * 4 * sizeof(double), b_e = (size_t)N * c.max_entries * 20 * sizeof(double);
-    int rc = ensure_host_stage(h, b_cnt + b_ne + b_fl + b_k + b_e + 64);
+    const int WN = h->ws.N;                      // the block is laid out for the workspace's frame capacity
+    int rc = ensure_host_stage(h, h->ws.result_bytes + 64);
     if (rc) return rc;
-    char* p = (char*)h->h_stage;
-    unsigned long long* h_fl = (unsigned long long*)p; p += b_fl;
-    double* h_k = (double*)p; p += b_k;
-    double* h_e = (double*)p; p += b_e;
-    int* h_cnt = (int*)p; p += b_cnt;
-    int* h_ne = (int*)p;
-    HIP_TRY(h, hipMemcpyAsync(h_fl, h->ws.flags, b_fl, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h_cnt, h->ws.kpt_count, b_cnt, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h_ne, h->ws.n_entries, b_ne, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h_k, h->ws.kpts_out, b_k, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h_e, h->ws.entries, b_e, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->h_stage, h->ws.result_block, h->ws.result_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    char* p = (char*)h->h_stage;
+    const unsigned long long* h_fl = (const unsigned long long*)p; p += (size_t)WN * 4 * 8;
+    const double* h_k = (const double*)p; p += (size_t)WN * 18 * c.max_kpts * 4 * 8;
+    const double* h_e = (const double*)p; p += (size_t)WN * c.max_entries * 20 * 8;
+    const int* h_cnt = (const int*)p; p += (size_t)WN * 18 * 4;
+    const int* h_ne = (const int*)p;
     for (int f = 0; f < N; ++f) {
         if (h_fl[f * 4 + 0]) {
             char msg[160];

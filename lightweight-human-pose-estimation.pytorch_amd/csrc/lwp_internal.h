@@ -19,7 +19,7 @@ struct ParamSpec {
 std::vector<ParamSpec> param_table(int nref, int C, int NH, int NP);
 
 // ------------------------------------------------------------------ layer graph
-enum LayerKind { L_STEM = 0, L_DW = 1, L_GEMM = 2 };
+enum LayerKind { L_STEM = 0, L_DW = 1, L_GEMM = 2, L_DWPW = 3 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2 };
 enum KClass { KC_STEM = 0, KC_DW = 1, KC_PW = 2, KC_C3 = 3, KC_POST = 4, KC_OTHER = 5, KC_COUNT = 6 };
 
@@ -41,6 +41,10 @@ struct Layer {
     // packed weights (float offsets into the blob)
     size_t w_off = 0, b_off = 0;
     int cin_pad = 0, cout_pad = 0;
+    // L_DWPW: the pointwise half (conv_key/bn_key/act/stride/dil above describe the depthwise half)
+    std::string conv2_key, bn2_key;
+    int act2 = ACT_NONE;
+    size_t w2_off = 0, b2_off = 0;
 };
 
 struct BufSpec {
@@ -56,7 +60,7 @@ struct Graph {
     int cat_buf = -1;          // the [feat | heat | paf | pad] buffer
     int cat_channels = 0;
 };
-Graph build_graph(int nref, int C, int NH, int NP);
+Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw);
 
 struct HostTensor {
     const void* ptr;
@@ -92,6 +96,19 @@ struct GemmParams {
     const float* zeros;              // >= 16 bytes of zeros (source of out-of-image taps)
     int N, H, W, cin_pad, cout, cout_pad, ks, dil, act;
 };
+struct DwPwParams {
+    const float* in; int in_ld;          // depthwise input, NHWC
+    const float* dw_w;                   // [9][C] followed by [C] bias (contiguous)
+    const float* pw_w;                   // fragment-packed pointwise weights [C/32][cout/32][4][64][4]
+    const float* pw_b;                   // [cout]
+    float* out; int out_ld;
+    const float* res; int res_ld;        // may be null
+    const float* zeros;
+    int N, Hi, Wi, Ho, Wo, C, cout, stride, dil, act_dw, act_pw;
+    int debug = 0;                       // ablation switches (LWP_DWPW_DEBUG): 1 skip phase 1, 2 skip B loads, 4 skip MFMAs
+};
+bool dwpw_supported(int C, int cout);
+hipError_t launch_dwpw(const DwPwParams& p, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, hipStream_t s);
 hipError_t launch_dw(const DwParams& p, hipStream_t s);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
@@ -128,6 +145,8 @@ struct PostWorkspace {    // device buffers, sized for (N frames, caps)
     double* entries = nullptr;      // [N*max_entries*20]
     int* n_entries = nullptr;       // [N]
     double* kpts_out = nullptr;     // [N*18*max_kpts*4]
+    void* result_block = nullptr;   // flags, kpts_out, entries, kpt_count, n_entries: one allocation, one D2H copy
+    size_t result_bytes = 0;
 };
 
 hipError_t init_cubic_tables();

@@ -106,7 +106,7 @@ struct Builder {
 };
 }  // namespace
 
-Graph build_graph(int nref, int C, int NH, int NP) {
+Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw) {
     Builder b;
     Graph& g = b.g;
     g.nref = nref; g.C = C; g.NH = NH; g.NP = NP;
@@ -127,22 +127,42 @@ Graph build_graph(int nref, int C, int NH, int NP) {
     for (int i = 0; i < 11; ++i) {
         int cin = kBackbone[i][0], cout = kBackbone[i][1], st = kBackbone[i][2], dl = kBackbone[i][3];
         // blocks 4.. alternate X (dw out) / Y (pw out); block 4's dw reads p3 (level 2)
-        b.add(L_DW, fmt("model.%d.dw", i + 1), fmt("model.%d.0", i + 1), fmt("model.%d.1", i + 1), false, cin, cin, 3, st, dl,
-              ACT_RELU, Builder::ref(src, src_ld), Builder::ref(dwbuf[i], cin));
-        b.add(L_GEMM, fmt("model.%d.pw", i + 1), fmt("model.%d.3", i + 1), fmt("model.%d.4", i + 1), false, cin, cout, 1, 1, 1,
-              ACT_RELU, Builder::ref(dwbuf[i], cin), Builder::ref(pwbuf[i], cout));
+        if (fuse_dwpw && dwpw_supported(cin, cout)) {
+            // the fused kernel reads a 3x3 neighbourhood of `src` while other workgroups write: never in place
+            const int dstb = (pwbuf[i] == src) ? (src == Y ? X : Y) : pwbuf[i];
+            Layer& f = b.add(L_DWPW, fmt("model.%d.pw", i + 1), fmt("model.%d.0", i + 1), fmt("model.%d.1", i + 1), false, cin, cout, 3, st, dl,
+                             ACT_RELU, Builder::ref(src, src_ld), Builder::ref(dstb, cout));
+            f.conv2_key = fmt("model.%d.3", i + 1); f.bn2_key = fmt("model.%d.4", i + 1); f.act2 = ACT_RELU;
+            src = dstb; src_ld = cout;
+            continue;
+        } else {
+            b.add(L_DW, fmt("model.%d.dw", i + 1), fmt("model.%d.0", i + 1), fmt("model.%d.1", i + 1), false, cin, cin, 3, st, dl,
+                  ACT_RELU, Builder::ref(src, src_ld), Builder::ref(dwbuf[i], cin));
+            b.add(L_GEMM, fmt("model.%d.pw", i + 1), fmt("model.%d.3", i + 1), fmt("model.%d.4", i + 1), false, cin, cout, 1, 1, 1,
+                  ACT_RELU, Builder::ref(dwbuf[i], cin), Builder::ref(pwbuf[i], cout));
+        }
         src = pwbuf[i]; src_ld = cout;
     }
     // Cpm (with_mobilenet.py:18-21): a = align(x); feat = conv(a + trunk(a))
-    b.add(L_GEMM, "cpm.align", "cpm.align.0", "", true, 512, C, 1, 1, 1, ACT_RELU, Builder::ref(Y, 512), Builder::ref(S0, C));
+    b.add(L_GEMM, "cpm.align", "cpm.align.0", "", true, 512, C, 1, 1, 1, ACT_RELU, Builder::ref(src, 512), Builder::ref(S0, C));
     int tin = S0;
     for (int j = 0; j < 3; ++j) {
-        b.add(L_DW, fmt("cpm.trunk.%d.dw", j), fmt("cpm.trunk.%d.0", j), "", false, C, C, 3, 1, 1, ACT_ELU,
-              Builder::ref(tin, C), Builder::ref(S1, C));
-        Layer& pw = b.add(L_GEMM, fmt("cpm.trunk.%d.pw", j), fmt("cpm.trunk.%d.2", j), "", false, C, C, 1, 1, 1, ACT_ELU,
-                          Builder::ref(S1, C), Builder::ref(S2, C));
-        if (j == 2) pw.res = Builder::ref(S0, C);   // x + trunk(x), fused into the last pw's epilogue
-        tin = S2;
+        if (fuse_dwpw && dwpw_supported(C, C)) {
+            // S0 holds `a` (kept for the residual); the chain alternates S1/S2 and must END in S2
+            const int dstb = (j % 2 == 0) ? S2 : S1;
+            Layer& f = b.add(L_DWPW, fmt("cpm.trunk.%d.pw", j), fmt("cpm.trunk.%d.0", j), "", false, C, C, 3, 1, 1, ACT_ELU,
+                             Builder::ref(tin, C), Builder::ref(dstb, C));
+            f.conv2_key = fmt("cpm.trunk.%d.2", j); f.act2 = ACT_ELU;
+            if (j == 2) f.res = Builder::ref(S0, C);
+            tin = dstb;
+        } else {
+            b.add(L_DW, fmt("cpm.trunk.%d.dw", j), fmt("cpm.trunk.%d.0", j), "", false, C, C, 3, 1, 1, ACT_ELU,
+                  Builder::ref(tin, C), Builder::ref(S1, C));
+            Layer& pw = b.add(L_GEMM, fmt("cpm.trunk.%d.pw", j), fmt("cpm.trunk.%d.2", j), "", false, C, C, 1, 1, 1, ACT_ELU,
+                              Builder::ref(S1, C), Builder::ref(S2, C));
+            if (j == 2) pw.res = Builder::ref(S0, C);   // x + trunk(x), fused into the last pw's epilogue
+            tin = S2;
+        }
     }
     b.add(L_GEMM, "cpm.conv", "cpm.conv.0", "", true, C, C, 3, 1, 1, ACT_RELU, Builder::ref(S2, C), Builder::ref(CAT, catc, 0));
     // initial stage (with_mobilenet.py:41-45)
@@ -182,6 +202,14 @@ Graph build_graph(int nref, int C, int NH, int NP) {
         } else if (l.kind == L_DW) {
             l.cin_pad = l.cin; l.cout_pad = l.cout;
             l.w_off = off; off += (size_t)9 * l.cin;
+        } else if (l.kind == L_DWPW) {
+            l.cin_pad = l.cin; l.cout_pad = l.cout;
+            l.w_off = off; off += (size_t)9 * l.cin;          // depthwise [9][C] ...
+            l.b_off = off; off += l.cin;                      // ... immediately followed by its bias [C]
+            l.w2_off = off; off += (size_t)l.cin * l.cout;    // fragment-packed pointwise weights
+            l.b2_off = off; off += l.cout;
+            off = (off + 63) / 64 * 64;
+            continue;
         } else {
             l.cin_pad = round_up(l.cin, 32);
             l.cout_pad = round_up(l.cout, 64);
@@ -212,15 +240,15 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
     }
     auto f32 = [&](const std::string& k) { return (const float*)by_name[k]->ptr; };
     blob.assign(g.blob_floats, 0.0f);
-    for (const Layer& l : g.layers) {
-        const int co = l.cout;
-        std::vector<double> scale(co, 1.0), shift(co, 0.0);   // y = conv*scale + shift
-        const float* cb = l.has_bias ? f32(l.conv_key + ".bias") : nullptr;
-        if (!l.bn_key.empty()) {
-            const float* gam = f32(l.bn_key + ".weight");
-            const float* bet = f32(l.bn_key + ".bias");
-            const float* mu = f32(l.bn_key + ".running_mean");
-            const float* var = f32(l.bn_key + ".running_var");
+    auto fold = [&](const std::string& conv_key, const std::string& bn_key, bool has_bias, int co, std::vector<double>& scale,
+                    std::vector<double>& shift) {   // y = conv*scale + shift
+        scale.assign(co, 1.0); shift.assign(co, 0.0);
+        const float* cb = has_bias ? f32(conv_key + ".bias") : nullptr;
+        if (!bn_key.empty()) {
+            const float* gam = f32(bn_key + ".weight");
+            const float* bet = f32(bn_key + ".bias");
+            const float* mu = f32(bn_key + ".running_mean");
+            const float* var = f32(bn_key + ".running_var");
             for (int o = 0; o < co; ++o) {
                 scale[o] = (double)gam[o] / std::sqrt((double)var[o] + 1e-5);
                 shift[o] = ((cb ? (double)cb[o] : 0.0) - (double)mu[o]) * scale[o] + (double)bet[o];
@@ -228,6 +256,11 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
         } else if (cb) {
             for (int o = 0; o < co; ++o) shift[o] = cb[o];
         }
+    };
+    for (const Layer& l : g.layers) {
+        std::vector<double> scale, shift;
+        const int co = (l.kind == L_DWPW) ? l.cin : l.cout;   // channels of the FIRST conv of the layer
+        fold(l.conv_key, l.bn_key, l.has_bias, co, scale, shift);
         const float* w = f32(l.conv_key + ".weight");
         float* wp = blob.data() + l.w_off;
         float* bp = blob.data() + l.b_off;
@@ -237,7 +270,7 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
                 for (int ci = 0; ci < 3; ++ci)
                     for (int t = 0; t < 9; ++t)
                         wp[(t * 3 + ci) * 32 + o] = (float)((double)w[(o * 3 + ci) * 9 + t] * scale[o]);
-        } else if (l.kind == L_DW) {            // (C,1,3,3) -> [tap][C]
+        } else if (l.kind == L_DW || l.kind == L_DWPW) {   // (C,1,3,3) -> [tap][C]
             for (int c = 0; c < co; ++c)
                 for (int t = 0; t < 9; ++t) wp[(size_t)t * co + c] = (float)((double)w[c * 9 + t] * scale[c]);
         } else {                                // OIHW -> [tap][cout_pad][cin_pad]
@@ -247,6 +280,26 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
                     for (int t = 0; t < taps; ++t)
                         wp[((size_t)t * l.cout_pad + o) * l.cin_pad + ci] =
                             (float)((double)w[((size_t)o * l.cin + ci) * taps + t] * scale[o]);
+        }
+        if (l.kind == L_DWPW) {
+            // pointwise half: (cout, C, 1, 1) -> MFMA fragment order [C/32][cout/32][4][64 lanes][4]; lane (q = lane>>4,
+            // c = lane&15) holds value v = u*8 + j*2 + t  =  W[n = 32w + 16t + c][k = 32s + 16u + 4q + j]
+            std::vector<double> sc2, sh2;
+            fold(l.conv2_key, l.bn2_key, false, l.cout, sc2, sh2);
+            const float* w2 = f32(l.conv2_key + ".weight");
+            float* w2p = blob.data() + l.w2_off;
+            float* b2p = blob.data() + l.b2_off;
+            for (int o = 0; o < l.cout; ++o) b2p[o] = (float)sh2[o];
+            const int nw = l.cout / 32, C_ = l.cin;
+            for (int s = 0; s < C_ / 32; ++s)
+                for (int wv = 0; wv < nw; ++wv)
+                    for (int v = 0; v < 16; ++v)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int u = v >> 3, j = (v >> 1) & 3, t = v & 1, q = lane >> 4, c = lane & 15;
+                            const int k = 32 * s + 16 * u + 4 * q + j, n = 32 * wv + 16 * t + c;
+                            w2p[(((size_t)(s * nw + wv) * 4 + (v >> 2)) * 64 + lane) * 4 + (v & 3)] =
+                                (float)((double)w2[(size_t)n * C_ + k] * sc2[n]);
+                        }
         }
     }
     return "";

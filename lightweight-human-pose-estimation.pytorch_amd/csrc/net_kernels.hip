@@ -361,6 +361,175 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     return dispatch_gemm(p, s, c);
 }
 
+// ---------------------------------------------------------------------------------------- fused depthwise -> pointwise
+// conv_dw / conv_dw_no_bn blocks (modules/conv.py:13-32) as ONE kernel: the depthwise 3x3 (+BN+ReLU | +ELU) output
+// never goes to memory and one launch replaces two.
+//   workgroup = BM output pixels x ALL output channels: NW waves, wave w owns channels [32w, 32w+32) as
+//   (BM/16) x 2 accumulators of v_mfma_f32_16x16x4_f32 -> the depthwise result is computed exactly once per pixel.
+//   Phase 1: all NW*64 threads compute the workgroup's whole depthwise row block [BM][C] into LDS (one round of
+//            coalesced 16-byte loads: consecutive lanes on consecutive channels), one barrier.
+//   Phase 2: barrier-free GEMM over K = C from the resident tile: a lane (row r = lane&15, q = lane>>4) reads
+//            k = 16u+4q..+3 with one ds_read_b128; MFMA (u,j) contracts k in {16u+4q+j}.  B (pointwise weights)
+//            never touches LDS: it is packed on the host in fragment order [k-step][wave][4][lane][4 floats], so each
+//            wave streams its own 4 KiB per 32-deep step from L2 with four fully coalesced 1-KiB loads, prefetched
+//            one step ahead in registers.  With 4 waves per SIMD and no barrier the matrix pipes stay fed.
+template <int BM, int NW>
+__global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
+    constexpr int NT = NW * 64;
+    constexpr int RT = BM / 16;                      // row tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int ldA = p.C + 4;                         // padded row stride (floats)
+    float* At = dsm;                                 // [BM][C + 4]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = blockIdx.y * NW + (tid >> 6);   // global column-wave index (blockIdx.y: column split)
+    const int nwt = gridDim.y * NW;                  // column waves in total = cout / 32
+    const int r16 = lane & 15, q = lane >> 4;
+    const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int nsteps = p.C / 32;
+
+    f32x4 bcur[4], bnxt[4], bnn[4];                 // weight fragments of steps s, s+1, s+2
+    auto load_b = [&](int step, f32x4* dst) {
+        const float* src = p.pw_w + ((int64_t)(step * nwt + wave) * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = *(const f32x4*)(src + j * 256);
+    };
+    load_b(0, bcur);                                 // in flight during phase 1
+    if (nsteps > 1) load_b(1, bnxt);
+
+    // ---- phase 1: depthwise row block.  A thread keeps ONE 4-channel chunk (its 9 weight vectors + bias are loaded
+    // once) and walks rows: NT is a multiple of C/4 for every layer shape, so the chunk is the same for all its rows.
+    const int cg = p.C >> 2;
+    if (!(p.debug & 1)) {
+        const int c = (tid % cg) * 4;
+        f32x4 wv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = *(const f32x4*)(p.dw_w + t * p.C + c);
+        const f32x4 bias = *(const f32x4*)(p.dw_w + 9 * p.C + c);
+        for (int row = tid / cg; row < BM; row += NT / cg) {
+            const int64_t m = m0 + row;
+            const bool ok = m < M;
+            const int64_t mm = ok ? m : 0;
+            const int xo = (int)(mm % p.Wo), yo = (int)((mm / p.Wo) % p.Ho);
+            const int64_t img = mm / ((int64_t)p.Wo * p.Ho);
+            const int yc = yo * p.stride, xc = xo * p.stride;
+            const float* base = p.in + ((img * p.Hi + yc) * p.Wi + xc) * p.in_ld + c;
+            f32x4 x[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
+                const bool in = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
+                const float* src = in ? base + ((int64_t)dy * p.Wi + dx) * p.in_ld : p.zeros;   // select on the address
+                x[t] = *(const f32x4*)src;
+            }
+            f32x4 acc = bias;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc += x[t] * wv[t];
+            acc.x = apply_act(acc.x, p.act_dw); acc.y = apply_act(acc.y, p.act_dw);
+            acc.z = apply_act(acc.z, p.act_dw); acc.w = apply_act(acc.w, p.act_dw);
+            *(f32x4*)(At + row * ldA + c) = acc;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: pointwise GEMM, no barriers
+    f32x4 acc[RT][2];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float* a_lane = At + r16 * ldA + 4 * q;
+    for (int step = 0; step < nsteps; ++step) {
+        const bool more = step + 1 < nsteps;
+        if (step + 2 < nsteps && !(p.debug & 2)) load_b(step + 2, bnn);
+        if (p.debug & 4) continue;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 av[RT];
+#pragma unroll
+            for (int a = 0; a < RT; ++a) av[a] = *(const f32x4*)(a_lane + a * 16 * ldA + step * 32 + 16 * u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // packed B value index v = u*8 + j*2 + t  ->  register bcur[v >> 2][v & 3]
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int v = u * 8 + j * 2 + t;
+                    const float b = bcur[v >> 2][v & 3];
+#pragma unroll
+                    for (int a = 0; a < RT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], b, acc[a][t], 0, 0, 0);
+                }
+            }
+        }
+        if (more && !(p.debug & 2)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bcur[j] = bnxt[j]; bnxt[j] = bnn[j]; }
+        }
+    }
+    // epilogue: D layout col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = wave * 32 + t * 16 + r16;
+        const float bias = p.pw_b[n];
+#pragma unroll
+        for (int a = 0; a < RT; ++a) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t m = m0 + a * 16 + q * 4 + g;
+                if (m < M) {
+                    float v = apply_act(acc[a][t][g] + bias, p.act_pw);
+                    if (p.res) v += p.res[m * p.res_ld + n];
+                    p.out[m * p.out_ld + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int NW>
+static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
+    const size_t lds = (size_t)BM * (p.C + 4) * sizeof(float);
+    const int nsplit = (p.cout / 32) / NW;
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)dwpw_kernel<BM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((dwpw_kernel<BM, NW>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+bool dwpw_supported(int C, int cout) {
+    return C % 32 == 0 && (cout == 64 || cout == 128 || cout == 256 || cout == 512);
+}
+
+hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
+    DwPwParams p = p_in;
+    static const char* dbg = getenv("LWP_DWPW_DEBUG");
+    p.debug = dbg ? atoi(dbg) : 0;
+    const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
+    const int nw = p.cout / 32;
+    // rows per workgroup: 16 keeps >= ~1 workgroup per CU at batch 1; larger tiles amortise the weight stream when
+    // there are many pixels.  (BM*8 depthwise items must fit 2 per thread: BM <= 16*NW.)
+    int bm = 16;
+    if (M / 16 >= 4096) bm = 32;
+    if (M / 32 >= 4096) bm = 64;
+    int nw_wg = nw;                                  // waves per workgroup (column split = nw / nw_wg)
+    static const char* env = getenv("LWP_DWPW_BM");
+    static const char* env2 = getenv("LWP_DWPW_NW");
+    if (env) bm = atoi(env);
+    if (env2 && atoi(env2) < nw && nw % atoi(env2) == 0) nw_wg = atoi(env2);
+    if (bm > 64) bm = 64;
+    while (bm > 16 && (size_t)bm * (p.C + 4) * sizeof(float) > 150 * 1024) bm >>= 1;
+#define DP_CASE(BM_, NW_) if (bm == BM_ && nw_wg == NW_) return launch_dwpw_t<BM_, NW_>(p, s);
+    DP_CASE(16, 2) DP_CASE(32, 2) DP_CASE(64, 2)
+    DP_CASE(16, 4) DP_CASE(32, 4) DP_CASE(64, 4)
+    DP_CASE(16, 8) DP_CASE(32, 8) DP_CASE(64, 8)
+    DP_CASE(16, 16) DP_CASE(32, 16) DP_CASE(64, 16)
+#undef DP_CASE
+    return hipErrorInvalidValue;
+}
+
 // ---------------------------------------------------------------------------------------- layout helper
 __global__ void __launch_bounds__(256) nchw_from_nhwc_kernel(const float* src, int src_ld, float* dst, int N, int HW, int C) {
     const int64_t total = (int64_t)N * C * HW;
