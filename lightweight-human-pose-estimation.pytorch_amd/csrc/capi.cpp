@@ -28,6 +28,7 @@ struct lwp_context {
     std::vector<size_t> d_outs_bytes;
     float* d_tmp = nullptr; size_t d_tmp_bytes = 0;     // generic device staging (upsample / extract / group)
     float* d_tmp2 = nullptr; size_t d_tmp2_bytes = 0;
+    float* d_maps[2] = {nullptr, nullptr}; size_t d_maps_bytes[2] = {0, 0};   // bf16 path: f32 NCHW heat / PAF of the last stage
     // post-processing
     PostCaps caps;
     PostWorkspace ws;
@@ -112,7 +113,7 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
     h->dtype = dtype;
     {
         const char* fe = getenv("LWP_FUSE_DWPW");   // "0" keeps depthwise and pointwise as separate launches (A/B, tests)
-        h->g = build_graph(nref, C, NH, NP, !(fe && fe[0] == '0'));
+        h->g = build_graph(nref, C, NH, NP, !(fe && fe[0] == '0'), dtype);
     }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
@@ -149,6 +150,7 @@ extern "C" int lwp_destroy(lwp_handle h) {
     if (h->d_in) (void)hipFree(h->d_in);
     if (h->d_tmp) (void)hipFree(h->d_tmp);
     if (h->d_tmp2) (void)hipFree(h->d_tmp2);
+    for (float* p : h->d_maps) if (p) (void)hipFree(p);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -225,7 +227,7 @@ static int ensure_activations(lwp_context* h, int N, int H, int W) {
         if (h->bufs[i]) { HIP_TRY(h, hipFree(h->bufs[i])); h->bufs[i] = nullptr; }
         int bh, bw;
         level_dims(H, W, h->g.bufs[i].level, &bh, &bw);
-        const size_t bytes = (size_t)N * bh * bw * h->g.bufs[i].channels * sizeof(float);
+        const size_t bytes = (size_t)N * bh * bw * h->g.bufs[i].channels * (h->dtype == LWP_BF16 ? 2 : 4);
         HIP_TRY(h, hipMalloc((void**)&h->bufs[i], bytes));
         // the concat buffer's pad channels must hold finite values (their weights are zero)
         HIP_TRY(h, hipMemsetAsync(h->bufs[i], 0, bytes, h->stream));
@@ -314,44 +316,50 @@ static int prof_end(lwp_context* h) {
     } while (0)
 
 // ---------------------------------------------------------------------------------------------- forward
+// element-addressed window of an activation buffer (f32 or bf16 storage)
+static inline float* buf_at(lwp_context* h, const BufRef& r) {
+    return (float*)((char*)h->bufs[r.buf] + (size_t)r.coff * (h->dtype == LWP_BF16 ? 2 : 4));
+}
+
 static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int N, int H, int W, float* const* d_outs_nchw) {
     const Graph& g = h->g;
+    const bool h16 = h->dtype == LWP_BF16;
     const float* wts = h->d_blob + l.w_off;
     const float* bias = h->d_blob + l.b_off;
     int dh, dw;
     level_dims(H, W, g.bufs[l.dst.buf].level, &dh, &dw);
-    float* dst = h->bufs[l.dst.buf] + l.dst.coff;
+    float* dst = buf_at(h, l.dst);
     if (l.kind == L_STEM) {
         StemParams p{d_in, wts, bias, dst, N, H, W, dh, dw};
-        LAUNCH(h, KC_STEM, launch_stem(p, h->stream));
+        LAUNCH(h, KC_STEM, h16 ? launch_stem_bf16(p, h->stream) : launch_stem(p, h->stream));
     } else if (l.kind == L_DWPW) {
         int sh, sw;
         level_dims(H, W, g.bufs[l.src.buf].level, &sh, &sw);
         DwPwParams p;
-        p.in = h->bufs[l.src.buf] + l.src.coff; p.in_ld = l.src.ld;
+        p.in = buf_at(h, l.src); p.in_ld = l.src.ld;
         p.dw_w = wts; p.pw_w = h->d_blob + l.w2_off; p.pw_b = h->d_blob + l.b2_off;
         p.out = dst; p.out_ld = l.dst.ld;
-        p.res = l.res.buf >= 0 ? h->bufs[l.res.buf] + l.res.coff : nullptr; p.res_ld = l.res.ld;
+        p.res = l.res.buf >= 0 ? buf_at(h, l.res) : nullptr; p.res_ld = l.res.ld;
         p.zeros = h->d_zeros;
         p.N = N; p.Hi = sh; p.Wi = sw; p.Ho = dh; p.Wo = dw; p.C = l.cin; p.cout = l.cout;
         p.stride = l.stride; p.dil = l.dil; p.act_dw = l.act; p.act_pw = l.act2;
-        LAUNCH(h, KC_PW, launch_dwpw(p, h->stream));
+        LAUNCH(h, KC_PW, h16 ? launch_dwpw_bf16(p, h->stream) : launch_dwpw(p, h->stream));
     } else if (l.kind == L_DW) {
         int sh, sw;
         level_dims(H, W, g.bufs[l.src.buf].level, &sh, &sw);
-        DwParams p{h->bufs[l.src.buf] + l.src.coff, l.src.ld, wts, bias, dst, l.dst.ld, N, sh, sw, dh, dw, l.cin, l.stride, l.dil, l.act};
+        DwParams p{buf_at(h, l.src), l.src.ld, wts, bias, dst, l.dst.ld, N, sh, sw, dh, dw, l.cin, l.stride, l.dil, l.act};
         LAUNCH(h, KC_DW, launch_dw(p, h->stream));
     } else {
         GemmParams p;
-        p.in = h->bufs[l.src.buf] + l.src.coff; p.in_ld = l.src.ld;
+        p.in = buf_at(h, l.src); p.in_ld = l.src.ld;
         p.w = wts; p.bias = bias;
         p.out = dst; p.out_ld = l.dst.ld;
-        p.res = l.res.buf >= 0 ? h->bufs[l.res.buf] + l.res.coff : nullptr; p.res_ld = l.res.ld;
+        p.res = l.res.buf >= 0 ? buf_at(h, l.res) : nullptr; p.res_ld = l.res.ld;
         p.out_nchw = (l.out_index >= 0 && d_outs_nchw) ? d_outs_nchw[l.out_index] : nullptr;
         p.zeros = h->d_zeros;
         p.N = N; p.H = dh; p.W = dw;
         p.cin_pad = l.cin_pad; p.cout = l.cout; p.cout_pad = l.cout_pad; p.ks = l.ks; p.dil = l.dil; p.act = l.act;
-        LAUNCH(h, l.ks == 1 ? KC_PW : KC_C3, launch_gemm(p, h->stream));
+        LAUNCH(h, l.ks == 1 ? KC_PW : KC_C3, h16 ? launch_gemm_bf16(p, h->stream) : launch_gemm(p, h->stream));
     }
     return LWP_OK;
 }
@@ -573,13 +581,32 @@ extern "C" int lwp_group_keypoints(lwp_handle h, const double* kpts, const int* 
 
 // ---------------------------------------------------------------------------------------------- fused pipeline
 static int enqueue_poses(lwp_context* h, const float* d_in, int N, int H, int W, int ratio, int demo, bool with_post) {
-    int rc = enqueue_forward(h, d_in, N, H, W, nullptr);
-    if (rc || !with_post) return rc;
     const Graph& g = h->g;
     const int fh = H / 8, fw = W / 8, cc = g.cat_channels;
-    const float* cat = h->bufs[g.cat_buf];
-    MapView heat{cat + g.C, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
-    MapView paf{cat + g.C + g.NH, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
+    MapView heat, paf;
+    if (h->dtype == LWP_BF16) {
+        // the concat buffer is bf16: the last stage's heads ALSO write f32 NCHW maps for the post-processing
+        const int nout = 2 * (1 + g.nref);
+        std::vector<float*> outs(nout, nullptr);
+        const size_t hb = (size_t)N * g.NH * fh * fw * sizeof(float), pb = (size_t)N * g.NP * fh * fw * sizeof(float);
+        int rc = ensure_dev(h, &h->d_maps[0], &h->d_maps_bytes[0], hb);
+        if (rc) return rc;
+        rc = ensure_dev(h, &h->d_maps[1], &h->d_maps_bytes[1], pb);
+        if (rc) return rc;
+        outs[nout - 2] = h->d_maps[0];
+        outs[nout - 1] = h->d_maps[1];
+        rc = enqueue_forward(h, d_in, N, H, W, outs.data());
+        if (rc || !with_post) return rc;
+        const int64_t hw = (int64_t)fh * fw;
+        heat = MapView{h->d_maps[0], (int64_t)g.NH * hw, (int64_t)fw, 1, hw, fh, fw};
+        paf = MapView{h->d_maps[1], (int64_t)g.NP * hw, (int64_t)fw, 1, hw, fh, fw};
+    } else {
+        int rc = enqueue_forward(h, d_in, N, H, W, nullptr);
+        if (rc || !with_post) return rc;
+        const float* cat = h->bufs[g.cat_buf];
+        heat = MapView{cat + g.C, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
+        paf = MapView{cat + g.C + g.NH, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
+    }
     LAUNCH(h, KC_POST, launch_find_peaks(heat, N, 18, ratio, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_nms(N, 18, fh * ratio, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_score_pairs(paf, N, ratio, demo, h->ws, h->stream));
@@ -702,7 +729,8 @@ extern "C" int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int 
     rc = ensure_dev(h, &h->d_tmp, &h->d_tmp_bytes, n * sizeof(float));
     if (rc) return rc;
     // NHWC window (ld, coff) -> compact NCHW
-    HIP_TRY(h, launch_nchw_from_nhwc(h->bufs[l.dst.buf] + l.dst.coff, l.dst.ld, h->d_tmp, N, dh * dw, l.cout, h->stream));
+    if (h->dtype == LWP_BF16) HIP_TRY(h, launch_nchw_from_nhwc_bf16(buf_at(h, l.dst), l.dst.ld, h->d_tmp, N, dh * dw, l.cout, h->stream));
+    else HIP_TRY(h, launch_nchw_from_nhwc(buf_at(h, l.dst), l.dst.ld, h->d_tmp, N, dh * dw, l.cout, h->stream));
     HIP_TRY(h, hipMemcpyAsync(dst, h->d_tmp, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     out_dims[0] = N; out_dims[1] = l.cout; out_dims[2] = dh; out_dims[3] = dw;

@@ -59,8 +59,9 @@ struct Graph {
     size_t blob_floats = 0;
     int cat_buf = -1;          // the [feat | heat | paf | pad] buffer
     int cat_channels = 0;
+    int dtype = LWP_F32;       // storage / MFMA dtype of the conv stack (weights packed accordingly)
 };
-Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw);
+Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype);
 
 struct HostTensor {
     const void* ptr;
@@ -109,6 +110,11 @@ struct DwPwParams {
 };
 bool dwpw_supported(int C, int cout);
 hipError_t launch_dwpw(const DwPwParams& p, hipStream_t s);
+// bf16 storage path (net_kernels_bf16.hip): same parameter structs, activation / packed-weight pointers are bf16
+hipError_t launch_stem_bf16(const StemParams& p, hipStream_t s);
+hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s);
+hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s);
+hipError_t launch_nchw_from_nhwc_bf16(const void* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, hipStream_t s);
 hipError_t launch_dw(const DwParams& p, hipStream_t s);
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);

@@ -106,16 +106,18 @@ struct Builder {
 };
 }  // namespace
 
-Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw) {
+Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype) {
     Builder b;
     Graph& g = b.g;
-    g.nref = nref; g.C = C; g.NH = NH; g.NP = NP;
+    g.nref = nref; g.C = C; g.NH = NH; g.NP = NP; g.dtype = dtype;
+    const bool h16 = dtype == LWP_BF16;
+    if (h16) fuse_dwpw = true;                    // the bf16 path has no stand-alone depthwise kernel
     // level-1/2 buffers are single-use; level 3 ping-pongs two 512-channel slots and three C-channel slots
     int s1 = b.new_buf(1, 32), d1 = b.new_buf(1, 32), p1 = b.new_buf(1, 64);
     int d2 = b.new_buf(2, 64), p2 = b.new_buf(2, 128), d3 = b.new_buf(2, 128), p3 = b.new_buf(2, 128);
     int X = b.new_buf(3, 512), Y = b.new_buf(3, 512);
     int S0 = b.new_buf(3, C), S1 = b.new_buf(3, C), S2 = b.new_buf(3, C);
-    int catc = round_up(C + NH + NP, 32);
+    int catc = round_up(C + NH + NP, 64);
     int CAT = b.new_buf(3, catc);
     g.cat_buf = CAT; g.cat_channels = catc;
 
@@ -206,20 +208,28 @@ Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw) {
             l.cin_pad = l.cin; l.cout_pad = l.cout;
             l.w_off = off; off += (size_t)9 * l.cin;          // depthwise [9][C] ...
             l.b_off = off; off += l.cin;                      // ... immediately followed by its bias [C]
-            l.w2_off = off; off += (size_t)l.cin * l.cout;    // fragment-packed pointwise weights
+            l.w2_off = off; off += (size_t)l.cin * l.cout / (h16 ? 2 : 1);   // fragment-packed pointwise weights
             l.b2_off = off; off += l.cout;
             off = (off + 63) / 64 * 64;
             continue;
         } else {
-            l.cin_pad = round_up(l.cin, 32);
+            l.cin_pad = round_up(l.cin, h16 ? 64 : 32);
             l.cout_pad = round_up(l.cout, 64);
-            l.w_off = off; off += (size_t)l.ks * l.ks * l.cout_pad * l.cin_pad;
+            l.w_off = off; off += (size_t)l.ks * l.ks * l.cout_pad * l.cin_pad / (h16 ? 2 : 1);
         }
         l.b_off = off; off += l.cout_pad;
         off = (off + 63) / 64 * 64;
     }
     g.blob_floats = off;
     return g;
+}
+
+static inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x0040u);   // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
 }
 
 std::string pack_weights(const Graph& g, const std::vector<std::string>& names, const std::vector<HostTensor>& tensors,
@@ -273,13 +283,17 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
         } else if (l.kind == L_DW || l.kind == L_DWPW) {   // (C,1,3,3) -> [tap][C]
             for (int c = 0; c < co; ++c)
                 for (int t = 0; t < 9; ++t) wp[(size_t)t * co + c] = (float)((double)w[c * 9 + t] * scale[c]);
-        } else {                                // OIHW -> [tap][cout_pad][cin_pad]
+        } else {                                // OIHW -> [tap][cout_pad][cin_pad]  (f32 or bf16)
             const int taps = l.ks * l.ks;
+            uint16_t* wh = (uint16_t*)wp;
             for (int o = 0; o < co; ++o)
                 for (int ci = 0; ci < l.cin; ++ci)
-                    for (int t = 0; t < taps; ++t)
-                        wp[((size_t)t * l.cout_pad + o) * l.cin_pad + ci] =
-                            (float)((double)w[((size_t)o * l.cin + ci) * taps + t] * scale[o]);
+                    for (int t = 0; t < taps; ++t) {
+                        const float v = (float)((double)w[((size_t)o * l.cin + ci) * taps + t] * scale[o]);
+                        const size_t idx = ((size_t)t * l.cout_pad + o) * l.cin_pad + ci;
+                        if (g.dtype == LWP_BF16) wh[idx] = f32_to_bf16_rne(v);
+                        else wp[idx] = v;
+                    }
         }
         if (l.kind == L_DWPW) {
             // pointwise half: (cout, C, 1, 1) -> MFMA fragment order [C/32][cout/32][4][64 lanes][4]; lane (q = lane>>4,
@@ -291,6 +305,20 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
             float* b2p = blob.data() + l.b2_off;
             for (int o = 0; o < l.cout; ++o) b2p[o] = (float)sh2[o];
             const int nw = l.cout / 32, C_ = l.cin;
+            if (g.dtype == LWP_BF16) {
+                // bf16: MFMA 16x16x32 operand order [C/32][cout/32][2 tiles][64 lanes][8]; lane (q = lane>>4, i = lane&15)
+                // holds W[n = 32w + 16t + i][k = 32s + 8q + j], j = 0..7
+                uint16_t* wh = (uint16_t*)w2p;
+                for (int s = 0; s < C_ / 32; ++s)
+                    for (int wv = 0; wv < nw; ++wv)
+                        for (int t = 0; t < 2; ++t)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int k = 32 * s + 8 * (lane >> 4) + j, n = 32 * wv + 16 * t + (lane & 15);
+                                    wh[((((size_t)(s * nw + wv) * 2 + t) * 64 + lane) * 8) + j] =
+                                        f32_to_bf16_rne((float)((double)w2[(size_t)n * C_ + k] * sc2[n]));
+                                }
+            } else {
             for (int s = 0; s < C_ / 32; ++s)
                 for (int wv = 0; wv < nw; ++wv)
                     for (int v = 0; v < 16; ++v)
@@ -300,6 +328,7 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
                             w2p[(((size_t)(s * nw + wv) * 4 + (v >> 2)) * 64 + lane) * 4 + (v & 3)] =
                                 (float)((double)w2[(size_t)n * C_ + k] * sc2[n]);
                         }
+            }
         }
     }
     return "";

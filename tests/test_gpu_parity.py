@@ -345,3 +345,73 @@ def test_drop_in_run_demo_fused_equals_stepwise():
         assert len(fa) == len(fb) and len(fa) >= 2
         for (ka, ca, ba), (kb, cb, bb) in zip(fa, fb):
             assert np.array_equal(ka, kb) and ca == cb and ba == bb
+
+
+# ------------------------------------------------------------------------------------------ bf16 path (config 3)
+# bf16 keeps 8 significant bits: ~0.2-0.4 % rounding per layer, ~50 layers deep.  Documented tolerance:
+# max-abs <= 0.15 * scale and mean-abs <= 0.02 * scale with scale = max(1, max|reference|) of the tensor compared.
+BF16_TOL = 0.15
+BF16_MEAN = 0.02
+
+
+def _bf16_net(nref=1, seed=1, calibrated=False):
+    from lwpose_amd import workload
+    if calibrated:
+        return workload.build_net(nref=nref, seed=seed, device=0, dtype="bf16")
+    net = PoseEstimationWithMobileNet(num_refinement_stages=nref, dtype="bf16")
+    sd = synth.make_state_dict(nref, seed=seed)
+    load_state(net, {"state_dict": sd})
+    return net.eval().cuda(), sd
+
+
+@pytest.mark.parametrize("nref", [1, 3])
+def test_bf16_per_layer_and_outputs_within_documented_tolerance(nref):
+    net, sd = _bf16_net(nref)
+    x = net_input(2, 64, 96, seed=100)
+    taps = {}
+    outs = net_ref.forward(sd, torch.from_numpy(x), nref, taps)
+    eng = net.engine
+    checked = 0
+    for info in eng.layers():
+        nm = info["name"]
+        key = nm[:-3] if nm.endswith(".pw") and nm.startswith("model.") else (nm if nm in ("model.0", "cpm.align") or nm.startswith("initial_stage.trunk.") else ("cpm" if nm == "cpm.conv" else None))
+        if key is None or key not in taps:
+            continue
+        got = eng.debug_layer_output(x, info["index"])
+        ref = taps[key].numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= BF16_TOL * scale, nm
+        assert np.abs(got - ref).mean() <= BF16_MEAN * scale, nm
+        checked += 1
+    assert checked >= 15
+    got = net(x)
+    for g, o in zip(got, outs):
+        assert g.dtype == np.float32 and g.shape == tuple(o.shape)
+        sc = max(1.0, float(o.abs().max()))
+        assert np.abs(g - o.numpy()).max() <= BF16_TOL * sc
+        assert np.abs(g - o.numpy()).mean() <= BF16_MEAN * sc
+
+
+def test_bf16_full_frame_batch_and_fused_post_is_exact_on_its_own_maps():
+    net, sd = _bf16_net(1, 1, calibrated=True)
+    x = net_input(3, 368, 656, seed=0)
+    outs = net(x)
+    ref = net_ref.forward(sd, torch.from_numpy(x), 1)
+    for o, r in zip(outs, ref):
+        sc = max(1.0, float(r.abs().max()))
+        assert np.abs(o - r.numpy()).max() <= BF16_TOL * sc
+        assert np.abs(o - r.numpy()).mean() <= BF16_MEAN * sc
+    res = net.engine.infer_poses(x, 4, demo=True)
+    nk = 0
+    for f in range(3):
+        hu = post_ref.upsample_cubic(outs[-2][f].transpose(1, 2, 0), 4)
+        pu = post_ref.upsample_cubic(outs[-1][f].transpose(1, 2, 0), 4)
+        by_type, total = [], 0
+        for k in range(18):
+            total += post_ref.extract_keypoints(hu[:, :, k], by_type, total)
+        ent, allk = post_ref.group_keypoints(by_type, pu, demo=True)
+        e, a, c = res[f]
+        assert np.array_equal(a, np.asarray(allk, dtype=np.float64).reshape(-1, 4))
+        assert np.array_equal(e.reshape(-1, 20), np.asarray(ent, dtype=np.float64).reshape(-1, 20))
+        nk += total
+    assert nk > 100
