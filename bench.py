@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--nref", type=int, default=1)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short batch-8/32 fp32 and batch-32 bf16 measurements reported under other_configs")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -198,6 +200,29 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, x_np, args.nref, args.cpu_budget)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_extra_configs:
+            # the other BASELINE.json configs, same step definition, a few steps each (not the primary metric)
+            other = {}
+            for b, dt in ((8, "fp32"), (32, "fp32"), (32, "bf16")):
+                if (b, dt) == (args.batch, args.dtype):
+                    continue
+                if dt == args.dtype:
+                    net2, eng2 = net, eng
+                else:
+                    net2, _ = workload.build_net(args.nref, 1, local_rank, dt, args.height, args.width)
+                    eng2 = net2.engine
+                xb = torch.from_numpy(workload.normalized_input(synth.make_frames(b, args.height, args.width))).cuda(local_rank)
+                for _ in range(2):
+                    eng2.infer_poses_async(xb, 4, True); eng2.fetch_poses()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(8):
+                    eng2.infer_poses_async(xb, 4, True); eng2.fetch_poses()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter() - t1
+                other["batch%d_%s" % (b, dt)] = {"frames_per_s": 8 * b / t2, "ms_per_step": t2 / 8 * 1e3,
+                                                  "device_ms_per_step": eng2.time_pipeline(xb, 5, what=1) / 5.0}
+            out["other_configs"] = other
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
