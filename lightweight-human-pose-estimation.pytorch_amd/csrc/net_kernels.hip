@@ -25,43 +25,77 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // ---------------------------------------------------------------------------------------- stem
-// one thread = one output pixel x 4 output channels (8 threads per pixel -> 128-B row stores)
+// conv 3x3 stride 2, 3 -> 32 (+folded BN, ReLU) from the NCHW float input to NHWC (f32 or bf16).
+// One workgroup = 8 x 32 output pixels.  The (17 x 65) x 3 input region is loaded into LDS with coalesced row
+// loads (the first version gathered 27 scattered floats per thread and was bound by the texture addresser:
+// 62 % issue stalls in the PMC profile); one thread computes one pixel x all 32 channels with the weights
+// arriving through scalar loads (uniform addresses); results are transposed through LDS so the write-out is
+// 16 bytes per lane on consecutive addresses (4 KiB contiguous per tile row).
+constexpr int ST_TY = 8, ST_TX = 32;
+template <bool BF16>
 __global__ void __launch_bounds__(256) stem_kernel(StemParams p) {
-    const int64_t total = (int64_t)p.N * p.Ho * p.Wo * 8;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int og = (int)(idx & 7);
-    int64_t pix = idx >> 3;
-    const int xo = (int)(pix % p.Wo);
-    pix /= p.Wo;
-    const int yo = (int)(pix % p.Ho);
-    const int n = (int)(pix / p.Ho);
+    constexpr int IR = 2 * ST_TY + 1, IC = 2 * ST_TX + 1;          // 17 x 65 input region per channel
+    constexpr int OLD = BF16 ? 20 : 36;                            // staged row stride in dwords (80 B / 144 B)
+    __shared__ float s_in[3][IR][IC + 1];
+    __shared__ __attribute__((aligned(16))) float s_out[256 * OLD];
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.Wo + ST_TX - 1) / ST_TX;
+    const int x0 = (blockIdx.x % tiles_x) * ST_TX, y0 = (blockIdx.x / tiles_x) * ST_TY;
+    const int n = blockIdx.y;
     const float* in = p.in + (int64_t)n * 3 * p.H * p.W;
-    f32x4 acc = *(const f32x4*)(p.bias + og * 4);
+    for (int i = tid; i < 3 * IR * IC; i += 256) {
+        const int col = i % IC, r = (i / IC) % IR, c = i / (IC * IR);
+        const int yi = 2 * y0 - 1 + r, xi = 2 * x0 - 1 + col;
+        float v = 0.f;
+        if (yi >= 0 && yi < p.H && xi >= 0 && xi < p.W) v = in[((int64_t)c * p.H + yi) * p.W + xi];
+        s_in[c][r][col] = v;
+    }
+    __syncthreads();
+    const int ty = tid / ST_TX, tx = tid % ST_TX;
+    float acc[32];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int yi = yo * 2 - 1 + ky;
-        if (yi < 0 || yi >= p.H) continue;
+    for (int o = 0; o < 32; ++o) acc[o] = p.bias[o];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xi = xo * 2 - 1 + kx;
-            if (xi < 0 || xi >= p.W) continue;
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
-                const float v = in[((int64_t)ci * p.H + yi) * p.W + xi];
-                const f32x4 w = *(const f32x4*)(p.w + ((ky * 3 + kx) * 3 + ci) * 32 + og * 4);
-                acc += v * w;
+                const float v = s_in[ci][2 * ty + ky][2 * tx + kx];
+                const float* w = p.w + ((ky * 3 + kx) * 3 + ci) * 32;      // uniform address: scalar loads
+#pragma unroll
+                for (int o = 0; o < 32; ++o) acc[o] = fmaf(v, w[o], acc[o]);
             }
+    if (BF16) {
+        __bf16* so = (__bf16*)s_out + tid * (OLD * 2);
+#pragma unroll
+        for (int o = 0; o < 32; ++o) so[o] = (__bf16)fmaxf(acc[o], 0.f);
+    } else {
+        float* so = s_out + tid * OLD;
+#pragma unroll
+        for (int o = 0; o < 32; o += 4) *(f32x4*)(so + o) = f32x4{fmaxf(acc[o], 0.f), fmaxf(acc[o + 1], 0.f), fmaxf(acc[o + 2], 0.f), fmaxf(acc[o + 3], 0.f)};
+    }
+    __syncthreads();
+    constexpr int CPP = BF16 ? 4 : 8;                               // 16-byte chunks per pixel
+    for (int qd = tid; qd < 256 * CPP; qd += 256) {
+        const int pix = qd / CPP, part = qd % CPP;
+        const int yo = y0 + pix / ST_TX, xo = x0 + pix % ST_TX;
+        if (yo < p.Ho && xo < p.Wo) {
+            const f32x4 v = *(const f32x4*)(s_out + pix * OLD + part * 4);
+            char* dst = (char*)p.out + ((((int64_t)n * p.Ho + yo) * p.Wo + xo) * 32) * (BF16 ? 2 : 4) + part * 16;
+            *(f32x4*)dst = v;
         }
     }
-    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-    *(f32x4*)(p.out + (((int64_t)n * p.Ho + yo) * p.Wo + xo) * 32 + og * 4) = acc;
 }
 
 hipError_t launch_stem(const StemParams& p, hipStream_t s) {
-    const int64_t total = (int64_t)p.N * p.Ho * p.Wo * 8;
-    const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(stem_kernel, dim3(blocks), dim3(256), 0, s, p);
+    const int tiles = ((p.Wo + ST_TX - 1) / ST_TX) * ((p.Ho + ST_TY - 1) / ST_TY);
+    hipLaunchKernelGGL(stem_kernel<false>, dim3(tiles, p.N), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_stem_bf16(const StemParams& p, hipStream_t s) {
+    const int tiles = ((p.Wo + ST_TX - 1) / ST_TX) * ((p.Ho + ST_TY - 1) / ST_TY);
+    hipLaunchKernelGGL(stem_kernel<true>, dim3(tiles, p.N), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -389,17 +423,25 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int nsteps = p.C / 32;
 
-    f32x4 bcur[4], bnxt[4], bnn[4];                 // weight fragments of steps s, s+1, s+2
+    // weight fragments: PF statically rotated register buffers (the K loop is unrolled by PF, no register copies), so
+    // PF-1 steps of the weight stream stay in flight per wave (bandwidth-delay: ~250 KB must be in flight per CU)
+    constexpr int PF = 2;
+    f32x4 bw[PF][4];
     auto load_b = [&](int step, f32x4* dst) {
         const float* src = p.pw_w + ((int64_t)(step * nwt + wave) * 4) * 256 + lane * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = *(const f32x4*)(src + j * 256);
     };
-    load_b(0, bcur);                                 // in flight during phase 1
-    if (nsteps > 1) load_b(1, bnxt);
+#pragma unroll
+    for (int j = 0; j < PF - 1; ++j)
+        if (j < nsteps) load_b(j, bw[j]);            // in flight during phase 1
 
     // ---- phase 1: depthwise row block.  A thread keeps ONE 4-channel chunk (its 9 weight vectors + bias are loaded
-    // once) and walks rows: NT is a multiple of C/4 for every layer shape, so the chunk is the same for all its rows.
+    // once; NT is a multiple of C/4 for every layer shape) and walks groups of PXG consecutive output pixels.  When the
+    // group lies in one image row (stride 1, dilation 1) its pixels share a 3 x (PXG+2) input window: the kernel is
+    // bound by the NUMBER of vector-memory instructions (TA busy ~ kernel time in the PMC profile), not by bytes.
+    constexpr int PXG = 2;
+    static_assert(BM % PXG == 0, "row block must hold whole pixel groups");
     const int cg = p.C >> 2;
     if (!(p.debug & 1)) {
         const int c = (tid % cg) * 4;
@@ -407,28 +449,62 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) wv[t] = *(const f32x4*)(p.dw_w + t * p.C + c);
         const f32x4 bias = *(const f32x4*)(p.dw_w + 9 * p.C + c);
-        for (int row = tid / cg; row < BM; row += NT / cg) {
-            const int64_t m = m0 + row;
-            const bool ok = m < M;
-            const int64_t mm = ok ? m : 0;
+        for (int grp = tid / cg; grp < BM / PXG; grp += NT / cg) {
+            const int row0 = grp * PXG;
+            const int64_t m = m0 + row0;
+            const bool ok0 = m < M;
+            const int64_t mm = ok0 ? m : 0;
             const int xo = (int)(mm % p.Wo), yo = (int)((mm / p.Wo) % p.Ho);
             const int64_t img = mm / ((int64_t)p.Wo * p.Ho);
-            const int yc = yo * p.stride, xc = xo * p.stride;
-            const float* base = p.in + ((img * p.Hi + yc) * p.Wi + xc) * p.in_ld + c;
-            f32x4 x[9];
+            if (p.stride == 1 && p.dil == 1 && m + PXG <= M && xo + PXG <= p.Wo) {
+                const float* base = p.in + ((img * p.Hi + yo) * p.Wi + xo) * p.in_ld + c;
+                f32x4 win[3][PXG + 2];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
-                const bool in = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
-                const float* src = in ? base + ((int64_t)dy * p.Wi + dx) * p.in_ld : p.zeros;   // select on the address
-                x[t] = *(const f32x4*)src;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = yo + ky - 1;
+                    const bool rok = yy >= 0 && yy < p.Hi;
+#pragma unroll
+                    for (int j = 0; j < PXG + 2; ++j) {
+                        const int xx = xo + j - 1;
+                        const float* src = (rok && xx >= 0 && xx < p.Wi) ? base + ((int64_t)(ky - 1) * p.Wi + (j - 1)) * p.in_ld : p.zeros;
+                        win[ky][j] = *(const f32x4*)src;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PXG; ++i) {
+                    f32x4 acc = bias;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc += win[t / 3][i + t % 3] * wv[t];
+                    acc.x = apply_act(acc.x, p.act_dw); acc.y = apply_act(acc.y, p.act_dw);
+                    acc.z = apply_act(acc.z, p.act_dw); acc.w = apply_act(acc.w, p.act_dw);
+                    *(f32x4*)(At + (row0 + i) * ldA + c) = acc;
+                }
+                continue;
             }
-            f32x4 acc = bias;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc += x[t] * wv[t];
-            acc.x = apply_act(acc.x, p.act_dw); acc.y = apply_act(acc.y, p.act_dw);
-            acc.z = apply_act(acc.z, p.act_dw); acc.w = apply_act(acc.w, p.act_dw);
-            *(f32x4*)(At + row * ldA + c) = acc;
+            for (int i = 0; i < PXG; ++i) {           // general path: borders of the row block, stride 2, dilation 2
+                const int64_t mi = m0 + row0 + i;
+                const bool ok = mi < M;
+                const int64_t mq = ok ? mi : 0;
+                const int xi = (int)(mq % p.Wo), yi = (int)((mq / p.Wo) % p.Ho);
+                const int64_t im = mq / ((int64_t)p.Wo * p.Ho);
+                const int yc = yi * p.stride, xc = xi * p.stride;
+                const float* base = p.in + ((im * p.Hi + yc) * p.Wi + xc) * p.in_ld + c;
+                f32x4 x[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
+                    const bool in = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
+                    const float* src = in ? base + ((int64_t)dy * p.Wi + dx) * p.in_ld : p.zeros;   // select on the address
+                    x[t] = *(const f32x4*)src;
+                }
+                f32x4 acc = bias;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc += x[t] * wv[t];
+                acc.x = apply_act(acc.x, p.act_dw); acc.y = apply_act(acc.y, p.act_dw);
+                acc.z = apply_act(acc.z, p.act_dw); acc.w = apply_act(acc.w, p.act_dw);
+                *(f32x4*)(At + (row0 + i) * ldA + c) = acc;
+            }
         }
     }
     __syncthreads();
@@ -438,30 +514,31 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 #pragma unroll
     for (int a = 0; a < RT; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float* a_lane = At + r16 * ldA + 4 * q;
-    for (int step = 0; step < nsteps; ++step) {
-        const bool more = step + 1 < nsteps;
-        if (step + 2 < nsteps && !(p.debug & 2)) load_b(step + 2, bnn);
-        if (p.debug & 4) continue;
+    for (int s0 = 0; s0 < nsteps; s0 += PF) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4 av[RT];
+        for (int jb = 0; jb < PF; ++jb) {
+            const int step = s0 + jb;
+            if (step >= nsteps) break;
+            if (step + PF - 1 < nsteps && !(p.debug & 2)) load_b(step + PF - 1, bw[(jb + PF - 1) % PF]);
+            if (p.debug & 4) continue;
+            const f32x4* bcur = bw[jb];
 #pragma unroll
-            for (int a = 0; a < RT; ++a) av[a] = *(const f32x4*)(a_lane + a * 16 * ldA + step * 32 + 16 * u);
+            for (int u = 0; u < 2; ++u) {
+                f32x4 av[RT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // packed B value index v = u*8 + j*2 + t  ->  register bcur[v >> 2][v & 3]
+                for (int a = 0; a < RT; ++a) av[a] = *(const f32x4*)(a_lane + a * 16 * ldA + step * 32 + 16 * u);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int v = u * 8 + j * 2 + t;
-                    const float b = bcur[v >> 2][v & 3];
+                for (int j = 0; j < 4; ++j) {
+                    // packed B value index v = u*8 + j*2 + t  ->  register bcur[v >> 2][v & 3]
 #pragma unroll
-                    for (int a = 0; a < RT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], b, acc[a][t], 0, 0, 0);
+                    for (int t = 0; t < 2; ++t) {
+                        const int v = u * 8 + j * 2 + t;
+                        const float b = bcur[v >> 2][v & 3];
+#pragma unroll
+                        for (int a = 0; a < RT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], b, acc[a][t], 0, 0, 0);
+                    }
                 }
             }
-        }
-        if (more && !(p.debug & 2)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { bcur[j] = bnxt[j]; bnxt[j] = bnn[j]; }
         }
     }
     // epilogue: D layout col = lane&15, row = (lane>>4)*4 + reg

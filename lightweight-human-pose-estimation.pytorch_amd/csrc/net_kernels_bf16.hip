@@ -8,6 +8,7 @@
 // written with consecutive lanes on consecutive pixels.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "lwp_internal.h"
 
@@ -24,47 +25,7 @@ __device__ __forceinline__ float act_f(float v, int act) {
     return v;
 }
 
-// ---------------------------------------------------------------------------------------- stem
-// one thread = one output pixel x 8 output channels (4 threads per pixel -> 64-byte row stores)
-__global__ void __launch_bounds__(256) stem_bf16_kernel(StemParams p) {
-    const int64_t total = (int64_t)p.N * p.Ho * p.Wo * 4;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int og = (int)(idx & 3);
-    int64_t pix = idx >> 2;
-    const int xo = (int)(pix % p.Wo);
-    pix /= p.Wo;
-    const int yo = (int)(pix % p.Ho);
-    const int n = (int)(pix / p.Ho);
-    const float* in = p.in + (int64_t)n * 3 * p.H * p.W;
-    f32x4 a0 = *(const f32x4*)(p.bias + og * 8), a1 = *(const f32x4*)(p.bias + og * 8 + 4);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int yi = yo * 2 - 1 + ky;
-        if (yi < 0 || yi >= p.H) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xi = xo * 2 - 1 + kx;
-            if (xi < 0 || xi >= p.W) continue;
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const float v = in[((int64_t)ci * p.H + yi) * p.W + xi];
-                const float* w = p.w + ((ky * 3 + kx) * 3 + ci) * 32 + og * 8;
-                a0 += v * *(const f32x4*)w;
-                a1 += v * *(const f32x4*)(w + 4);
-            }
-        }
-    }
-    bf16x8 o;
-    o[0] = (__bf16)fmaxf(a0.x, 0.f); o[1] = (__bf16)fmaxf(a0.y, 0.f); o[2] = (__bf16)fmaxf(a0.z, 0.f); o[3] = (__bf16)fmaxf(a0.w, 0.f);
-    o[4] = (__bf16)fmaxf(a1.x, 0.f); o[5] = (__bf16)fmaxf(a1.y, 0.f); o[6] = (__bf16)fmaxf(a1.z, 0.f); o[7] = (__bf16)fmaxf(a1.w, 0.f);
-    *(bf16x8*)((__bf16*)p.out + (((int64_t)n * p.Ho + yo) * p.Wo + xo) * 32 + og * 8) = o;
-}
-hipError_t launch_stem_bf16(const StemParams& p, hipStream_t s) {
-    const int64_t total = (int64_t)p.N * p.Ho * p.Wo * 4;
-    hipLaunchKernelGGL(stem_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
+// (the stem kernel is the <true> instantiation of stem_kernel in net_kernels.hip)
 
 // ---------------------------------------------------------------------------------------- fused depthwise -> pointwise
 // Same two-phase structure as the f32 kernel (net_kernels.hip): phase 1 computes the workgroup's depthwise row block
@@ -89,15 +50,24 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int nsteps = p.C / 32;
 
-    bf16x8 bcur[2], bnxt[2];
+    // weight fragments: PF statically rotated register buffers (K loop unrolled by PF, no copies): PF-1 steps of the
+    // weight stream stay in flight per wave — the bf16 MFMA phase is far too short to hide a 1-step prefetch
+    constexpr int PF = 2;
+    bf16x8 bw[PF][2];
     auto load_b = [&](int step, bf16x8* dst) {
         const __bf16* src = pw + ((int64_t)(step * nwt + wave) * 2) * 512 + lane * 8;
         dst[0] = *(const bf16x8*)src;
         dst[1] = *(const bf16x8*)(src + 512);
     };
-    load_b(0, bcur);
+#pragma unroll
+    for (int j = 0; j < PF - 1; ++j)
+        if (j < nsteps) load_b(j, bw[j]);
 
-    // ---- phase 1: one 4-channel chunk per thread (its 9 weight vectors + bias stay in registers), rows strided
+    // ---- phase 1: one 4-channel chunk per thread (its 9 weight vectors + bias stay in registers), walking groups of
+    // PXG consecutive output pixels; inside one image row (stride 1, dilation 1) the group shares a 3 x (PXG+2) input
+    // window — the kernel is bound by the number of vector-memory instructions (TA busy ~ kernel time), not by bytes.
+    constexpr int PXG = 4;
+    static_assert(BM % PXG == 0, "row block must hold whole pixel groups");
     const int cg = p.C >> 2;
     {
         const int c = (tid % cg) * 4;
@@ -105,30 +75,70 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) wv[t] = *(const f32x4*)(p.dw_w + t * p.C + c);
         const f32x4 bias = *(const f32x4*)(p.dw_w + 9 * p.C + c);
-        for (int row = tid / cg; row < BM; row += NT / cg) {
-            const int64_t m = m0 + row;
-            const bool ok = m < M;
-            const int64_t mm = ok ? m : 0;
-            const int xo = (int)(mm % p.Wo), yo = (int)((mm / p.Wo) % p.Ho);
-            const int64_t img = mm / ((int64_t)p.Wo * p.Ho);
-            const int yc = yo * p.stride, xc = xo * p.stride;
-            const __bf16* base = in + ((img * p.Hi + yc) * p.Wi + xc) * p.in_ld + c;
-            bf16x4 x[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
-                const bool inb = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
-                const __bf16* src = inb ? base + ((int64_t)dy * p.Wi + dx) * p.in_ld : (const __bf16*)p.zeros;
-                x[t] = *(const bf16x4*)src;
-            }
-            f32x4 a = bias;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const f32x4 v = {(float)x[t][0], (float)x[t][1], (float)x[t][2], (float)x[t][3]};
-                a += v * wv[t];
-            }
+        auto finish = [&](f32x4 a, int row) {
             const bf16x4 o = {(__bf16)act_f(a.x, p.act_dw), (__bf16)act_f(a.y, p.act_dw), (__bf16)act_f(a.z, p.act_dw), (__bf16)act_f(a.w, p.act_dw)};
             *(bf16x4*)(At + row * ldA + c) = o;
+        };
+        for (int grp = tid / cg; grp < BM / PXG; grp += NT / cg) {
+            const int row0 = grp * PXG;
+            const int64_t m = m0 + row0;
+            const int64_t mm = m < M ? m : 0;
+            const int xo = (int)(mm % p.Wo), yo = (int)((mm / p.Wo) % p.Ho);
+            const int64_t img = mm / ((int64_t)p.Wo * p.Ho);
+            if (p.stride == 1 && p.dil == 1 && m + PXG <= M && xo + PXG <= p.Wo) {
+                const __bf16* base = in + ((img * p.Hi + yo) * p.Wi + xo) * p.in_ld + c;
+                bf16x4 win[3][PXG + 2];                 // shared 3 x (PXG + 2) input window
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = yo + ky - 1;
+                    const bool rok = yy >= 0 && yy < p.Hi;
+#pragma unroll
+                    for (int j = 0; j < PXG + 2; ++j) {
+                        const int xx = xo + j - 1;
+                        const __bf16* src = (rok && xx >= 0 && xx < p.Wi) ? base + ((int64_t)(ky - 1) * p.Wi + (j - 1)) * p.in_ld : (const __bf16*)p.zeros;
+                        win[ky][j] = *(const bf16x4*)src;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < PXG; ++i) {
+                    f32x4 a = bias;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const bf16x4 w4 = win[t / 3][i + t % 3];
+                        const f32x4 v = {(float)w4[0], (float)w4[1], (float)w4[2], (float)w4[3]};
+                        a += v * wv[t];
+                    }
+                    finish(a, row0 + i);
+                }
+                continue;
+            }
+            // (a shared window for dilation 2 was tried: its 24 live vectors spill at the 128-VGPR cap of the 16-wave
+            //  workgroups and slowed every layer by 30-40 %)
+#pragma unroll 1
+            for (int i = 0; i < PXG; ++i) {           // general path: borders of the row block, stride 2, dilation 2
+                const int64_t mi = m0 + row0 + i;
+                const bool ok = mi < M;
+                const int64_t mq = ok ? mi : 0;
+                const int xi = (int)(mq % p.Wo), yi = (int)((mq / p.Wo) % p.Ho);
+                const int64_t im = mq / ((int64_t)p.Wo * p.Ho);
+                const int yc = yi * p.stride, xc = xi * p.stride;
+                const __bf16* base = in + ((im * p.Hi + yc) * p.Wi + xc) * p.in_ld + c;
+                bf16x4 x[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
+                    const bool inb = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
+                    const __bf16* src = inb ? base + ((int64_t)dy * p.Wi + dx) * p.in_ld : (const __bf16*)p.zeros;
+                    x[t] = *(const bf16x4*)src;
+                }
+                f32x4 a = bias;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const f32x4 v = {(float)x[t][0], (float)x[t][1], (float)x[t][2], (float)x[t][3]};
+                    a += v * wv[t];
+                }
+                finish(a, row0 + i);
+            }
         }
     }
     __syncthreads();
@@ -138,16 +148,19 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
 #pragma unroll
     for (int a = 0; a < RT; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const __bf16* x_lane = At + i16 * ldA + 8 * q;
-    for (int step = 0; step < nsteps; ++step) {
-        const bool more = step + 1 < nsteps;
-        if (more) load_b(step + 1, bnxt);
+    for (int s0 = 0; s0 < nsteps; s0 += PF) {
 #pragma unroll
-        for (int a = 0; a < RT; ++a) {
-            const bf16x8 xv = *(const bf16x8*)(x_lane + a * 16 * ldA + step * 32);
-            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[0], xv, acc[a][0], 0, 0, 0);
-            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bcur[1], xv, acc[a][1], 0, 0, 0);
+        for (int jb = 0; jb < PF; ++jb) {
+            const int step = s0 + jb;
+            if (step >= nsteps) break;
+            if (step + PF - 1 < nsteps) load_b(step + PF - 1, bw[(jb + PF - 1) % PF]);
+#pragma unroll
+            for (int a = 0; a < RT; ++a) {
+                const bf16x8 xv = *(const bf16x8*)(x_lane + a * 16 * ldA + step * 32);
+                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[jb][0], xv, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[jb][1], xv, acc[a][1], 0, 0, 0);
+            }
         }
-        if (more) { bcur[0] = bnxt[0]; bcur[1] = bnxt[1]; }
     }
     // epilogue
     __bf16* out = (__bf16*)p.out;
