@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--width", type=int, default=656)
     ap.add_argument("--nref", type=int, default=1)
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="serialise the steps (submit, wait, fetch) instead of the default two-slot streaming pipeline, "
+                         "in which the post-processing + host fetch of step k overlap the network of step k+1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short batch-8/32 fp32 and batch-32 bf16 measurements reported under other_configs")
@@ -131,14 +134,24 @@ def main():
         eng.infer_poses_async(x, 4, True)
         return eng.fetch_poses()
 
-    for _ in range(args.warmup):
-        res = step()
+    def run_steps(k):
+        """k complete passes (results of every pass fetched to the host)."""
+        if args.no_pipeline:
+            for _ in range(k):
+                r = step()
+            return r
+        for i in range(k):
+            eng.pipeline_submit(x, i & 1, 4, True)
+            if i > 0:
+                r = eng.pipeline_fetch((i - 1) & 1)
+        return eng.pipeline_fetch((k - 1) & 1)
+
+    res = run_steps(max(args.warmup, 1))
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    res = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -151,6 +164,11 @@ def main():
     if rank == 0:
         total_frames = world * args.batch * args.steps
         # device-only rates (HIP events on the engine's stream) and per-class launch times
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        for _ in range(20):
+            step()
+        latency_ms = (time.perf_counter() - tl) / 20 * 1e3       # serial step: submit, wait, fetch
         dev_ms = eng.time_pipeline(x, 20, what=1) / 20.0
         net_ms = eng.time_pipeline(x, 20, what=0) / 20.0
         classes = eng.profile_classes(x, reps=10)
@@ -190,9 +208,11 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d (frames sharded, no data-path collective)" % world},
             "roofline": roof,
             "roofline_classes": roofs,
+            "latency_ms_serial_step": latency_ms,
             "device_ms_per_step": {"pipeline": dev_ms, "network_only": net_ms, "post_only": max(dev_ms - net_ms, 0.0),
                                    "class_ms": {k: v["ms"] for k, v in classes.items()},
                                    "event_overhead_us_per_launch": ev_overhead_ms * 1e3},
+            "pipelined": not args.no_pipeline,
             "poses_per_frame": float(np.mean([len(r[0]) for r in res])),
             "keypoints_per_frame": float(np.mean([len(r[1]) for r in res])),
         }

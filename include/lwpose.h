@@ -137,6 +137,15 @@ int lwp_infer_poses_async(lwp_handle h, const float* in_device, int N, int H, in
 int lwp_fetch_poses(lwp_handle h, int* kpt_counts, double* kpts, int kpt_cap,
                     double* entries, int entry_cap, int* n_entries);
 
+/* ---- pipelined streaming (video): two result slots.  lwp_pipeline_submit enqueues the network of one batch on the
+ *      handle's main stream and its post-processing + result copy on a second stream, and returns at once;
+ *      lwp_pipeline_fetch(slot) waits for that slot only.  With submit(k) issued before fetch(k-1), the
+ *      post-processing and host fetch of batch k-1 overlap the network of batch k (replaces the strictly serial
+ *      frame loop of run_demo, demo.py:91-114; results are identical).  A slot must be fetched before it is reused. */
+int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, int H, int W, int upsample_ratio, int demo, int slot);
+int lwp_pipeline_fetch(lwp_handle h, int slot, int* kpt_counts, double* kpts, int kpt_cap,
+                       double* entries, int entry_cap, int* n_entries);
+
 /* ---- measurement helpers (bench.py): time `iters` back-to-back enqueues with HIP events on the
  *      handle's own stream.  what: 0 = forward only, 1 = full infer_poses.  ms_total out. */
 int lwp_time_pipeline(lwp_handle h, const float* in_device, int N, int H, int W, int upsample_ratio,

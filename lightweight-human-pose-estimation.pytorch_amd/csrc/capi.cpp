@@ -35,6 +35,16 @@ struct lwp_context {
     // pinned host staging for results
     void* h_stage = nullptr; size_t h_stage_bytes = 0;
     int last_N = 0;
+    // pipelined streaming mode: two result slots, post-processing + fetch of frame k overlap the network of frame k+1
+    struct Slot {
+        PostWorkspace ws;
+        float* maps[2] = {nullptr, nullptr}; size_t maps_bytes[2] = {0, 0};
+        void* h_stage = nullptr; size_t h_stage_bytes = 0;
+        hipEvent_t ev_maps = nullptr, ev_done = nullptr;
+        int N = 0;
+        bool pending = false;
+    } slots[2];
+    hipStream_t post_stream = nullptr;
     // per-launch profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;
@@ -131,8 +141,7 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
     return LWP_OK;
 }
 
-static void free_ws(lwp_context* h) {
-    PostWorkspace& w = h->ws;
+static void free_ws_obj(PostWorkspace& w) {
     // flags / kpt_count / n_entries / kpts_out / entries live in ONE allocation (result_block) so the fetch is one copy
     void* ptrs[] = {w.peak_count, w.peak_key, w.peak_val, w.kpt_xy, w.kpt_score, w.conn_count,
                     w.conn_ij, w.conn_ratio, w.result_block, w.sel_count, w.sel_ij, w.sel_r,
@@ -140,6 +149,7 @@ static void free_ws(lwp_context* h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = PostWorkspace();
 }
+static void free_ws(lwp_context* h) { free_ws_obj(h->ws); }
 
 extern "C" int lwp_destroy(lwp_handle h) {
     if (!h) return LWP_OK;
@@ -155,6 +165,15 @@ extern "C" int lwp_destroy(lwp_handle h) {
     if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     free_ws(h);
+    if (h->post_stream) (void)hipStreamSynchronize(h->post_stream);
+    for (auto& sl : h->slots) {
+        free_ws_obj(sl.ws);
+        for (float* p : sl.maps) if (p) (void)hipFree(p);
+        if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+        if (sl.ev_maps) (void)hipEventDestroy(sl.ev_maps);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
+    if (h->post_stream) (void)hipStreamDestroy(h->post_stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -169,6 +188,7 @@ extern "C" int lwp_set_capacity(lwp_handle h, int max_peaks, int max_kpts, int m
     (void)hipSetDevice(h->device);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     free_ws(h);
+    for (auto& sl : h->slots) { if (sl.pending) return fail(h, LWP_ERR_STATE, "pipeline slot pending"); free_ws_obj(sl.ws); }
     h->caps.max_peaks = max_peaks; h->caps.max_kpts = max_kpts; h->caps.max_conn = max_conn; h->caps.max_entries = max_entries;
     return LWP_OK;
 }
@@ -236,11 +256,10 @@ static int ensure_activations(lwp_context* h, int N, int H, int W) {
     return LWP_OK;
 }
 
-static int ensure_ws(lwp_context* h, int N) {
-    PostWorkspace& w = h->ws;
+static int ensure_ws_obj(lwp_context* h, PostWorkspace& w, int N, hipStream_t stream) {
     if (w.N >= N && w.peak_count) return LWP_OK;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    free_ws(h);
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    free_ws_obj(w);
     w.caps = h->caps;
     const PostCaps& c = h->caps;
 #define WS_ALLOC(field, count, type) HIP_TRY(h, hipMalloc((void**)&w.field, (size_t)(count) * sizeof(type)))
@@ -272,9 +291,10 @@ static int ensure_ws(lwp_context* h, int N) {
     WS_ALLOC(sel_sb, (size_t)N * 19 * c.max_kpts, float);
 #undef WS_ALLOC
     w.N = N;
-    HIP_TRY(h, launch_reset_ws(N, w, h->stream));
+    HIP_TRY(h, launch_reset_ws(N, w, stream));
     return LWP_OK;
 }
+static int ensure_ws(lwp_context* h, int N) { return ensure_ws_obj(h, h->ws, N, h->stream); }
 
 static int ensure_host_stage(lwp_context* h, size_t bytes) {
     if (h->h_stage_bytes >= bytes) return LWP_OK;
@@ -496,14 +516,22 @@ extern "C" int lwp_extract_keypoints(lwp_handle h, float* heatmap, int H, int W,
 }
 
 // ---------------------------------------------------------------------------------------------- results
+static int parse_results(lwp_context* h, const PostWorkspace& ws, const void* host_block, int N, int* kpt_counts, double* kpts,
+                         int kpt_cap, double* entries, int entry_cap, int* n_entries);
+
 static int fetch_results(lwp_context* h, int N, int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap, int* n_entries) {
-    const PostCaps& c = h->ws.caps;
-    const int WN = h->ws.N;                      // the block is laid out for the workspace's frame capacity
     int rc = ensure_host_stage(h, h->ws.result_bytes + 64);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->h_stage, h->ws.result_block, h->ws.result_bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    char* p = (char*)h->h_stage;
+    return parse_results(h, h->ws, h->h_stage, N, kpt_counts, kpts, kpt_cap, entries, entry_cap, n_entries);
+}
+
+static int parse_results(lwp_context* h, const PostWorkspace& ws, const void* host_block, int N, int* kpt_counts, double* kpts,
+                         int kpt_cap, double* entries, int entry_cap, int* n_entries) {
+    const PostCaps& c = ws.caps;
+    const int WN = ws.N;                         // the block is laid out for the workspace's frame capacity
+    const char* p = (const char*)host_block;
     const unsigned long long* h_fl = (const unsigned long long*)p; p += (size_t)WN * 4 * 8;
     const double* h_k = (const double*)p; p += (size_t)WN * 18 * c.max_kpts * 4 * 8;
     const double* h_e = (const double*)p; p += (size_t)WN * c.max_entries * 20 * 8;
@@ -656,6 +684,75 @@ extern "C" int lwp_infer_poses(lwp_handle h, const float* in, int in_mem, int N,
     return fetch_results(h, N, kpt_counts, kpts, kpt_cap, entries, entry_cap, n_entries);
 }
 
+// ---------------------------------------------------------------------------------------------- pipelined streaming
+extern "C" int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, int H, int W, int ratio, int demo, int slot) {
+    if (!h || !in_device || slot < 0 || slot > 1) return fail(h, LWP_ERR_ARG, "bad argument");
+    int rc = check_frame_shape(h, N, H, W);
+    if (rc) return rc;
+    if (ratio != 4 && ratio != 8) return fail(h, LWP_ERR_ARG, "upsample ratio must be 4 or 8");
+    if (h->g.NH < 18 || h->g.NP < 38) return fail(h, LWP_ERR_ARG, "pose grouping needs >= 18 heat-maps and >= 38 PAFs");
+    HIP_TRY(h, hipSetDevice(h->device));
+    lwp_context::Slot& sl = h->slots[slot];
+    if (sl.pending) return fail(h, LWP_ERR_STATE, "slot still pending: call lwp_pipeline_fetch first");
+    if (!h->post_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->post_stream, hipStreamNonBlocking));
+    if (!sl.ev_maps) {
+        HIP_TRY(h, hipEventCreateWithFlags(&sl.ev_maps, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+    }
+    rc = ensure_activations(h, N, H, W);
+    if (rc) return rc;
+    if (sl.ws.caps.max_peaks != h->caps.max_peaks || sl.ws.caps.max_kpts != h->caps.max_kpts) sl.ws.N = 0;   // (re)allocate lazily
+    rc = ensure_ws_obj(h, sl.ws, N, h->post_stream);
+    if (rc) return rc;
+    const Graph& g = h->g;
+    const int fh = H / 8, fw = W / 8;
+    const size_t hb = (size_t)N * g.NH * fh * fw * sizeof(float), pb = (size_t)N * g.NP * fh * fw * sizeof(float);
+    rc = ensure_dev(h, &sl.maps[0], &sl.maps_bytes[0], hb);
+    if (rc) return rc;
+    rc = ensure_dev(h, &sl.maps[1], &sl.maps_bytes[1], pb);
+    if (rc) return rc;
+    if (sl.h_stage_bytes < sl.ws.result_bytes) {
+        if (sl.h_stage) HIP_TRY(h, hipHostFree(sl.h_stage));
+        sl.h_stage = nullptr; sl.h_stage_bytes = 0;
+        HIP_TRY(h, hipHostMalloc(&sl.h_stage, sl.ws.result_bytes, hipHostMallocDefault));
+        sl.h_stage_bytes = sl.ws.result_bytes;
+    }
+    // network on the main stream: the last stage's heads also write f32 NCHW maps into this slot
+    const int nout = 2 * (1 + g.nref);
+    std::vector<float*> outs(nout, nullptr);
+    outs[nout - 2] = sl.maps[0];
+    outs[nout - 1] = sl.maps[1];
+    rc = enqueue_forward(h, in_device, N, H, W, outs.data());
+    if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(sl.ev_maps, h->stream));
+    // post-processing + result copy on the second stream
+    HIP_TRY(h, hipStreamWaitEvent(h->post_stream, sl.ev_maps, 0));
+    const int64_t hw = (int64_t)fh * fw;
+    MapView heat{sl.maps[0], (int64_t)g.NH * hw, (int64_t)fw, 1, hw, fh, fw};
+    MapView paf{sl.maps[1], (int64_t)g.NP * hw, (int64_t)fw, 1, hw, fh, fw};
+    HIP_TRY(h, launch_find_peaks(heat, N, 18, ratio, sl.ws, h->post_stream));
+    HIP_TRY(h, launch_nms(N, 18, fh * ratio, sl.ws, h->post_stream));
+    HIP_TRY(h, launch_score_pairs(paf, N, ratio, demo, sl.ws, h->post_stream));
+    HIP_TRY(h, launch_match(N, sl.ws, h->post_stream));
+    HIP_TRY(h, launch_assemble(N, sl.ws, h->post_stream));
+    HIP_TRY(h, hipMemcpyAsync(sl.h_stage, sl.ws.result_block, sl.ws.result_bytes, hipMemcpyDeviceToHost, h->post_stream));
+    HIP_TRY(h, hipEventRecord(sl.ev_done, h->post_stream));
+    sl.pending = true;
+    sl.N = N;
+    return LWP_OK;
+}
+
+extern "C" int lwp_pipeline_fetch(lwp_handle h, int slot, int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap,
+                                  int* n_entries) {
+    if (!h || slot < 0 || slot > 1 || !kpt_counts || !kpts || !entries || !n_entries) return fail(h, LWP_ERR_ARG, "bad argument");
+    lwp_context::Slot& sl = h->slots[slot];
+    if (!sl.pending) return fail(h, LWP_ERR_STATE, "nothing submitted on this slot");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(sl.ev_done));
+    sl.pending = false;
+    return parse_results(h, sl.ws, sl.h_stage, sl.N, kpt_counts, kpts, kpt_cap, entries, entry_cap, n_entries);
+}
+
 extern "C" int lwp_poses_from_maps(lwp_handle h, const float* heat, const float* paf, int mem, int N, int hs, int ws, int ratio,
                                    int demo, int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap,
                                    int* n_entries) {
@@ -767,6 +864,7 @@ extern "C" int lwp_synchronize(lwp_handle h) {
     if (!h) return LWP_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->post_stream) HIP_TRY(h, hipStreamSynchronize(h->post_stream));
     return LWP_OK;
 }
 

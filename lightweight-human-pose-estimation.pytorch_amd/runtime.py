@@ -215,6 +215,20 @@ class Engine(object):
                                     ecap, ne.ctypes.data_as(C.POINTER(C.c_int))), self.h.ptr)
         return self._unpack(N, counts, kpts, ent, ne)
 
+    # ------------------------------------------------------------------ pipelined streaming (two slots)
+    def pipeline_submit(self, x_cuda, slot, upsample_ratio=4, demo=True):
+        N, _, H, W = x_cuda.shape
+        self._keep_slot = getattr(self, "_keep_slot", {})
+        self._keep_slot[slot] = (x_cuda, N)
+        check(lib().lwp_pipeline_submit(self.h.ptr, x_cuda.data_ptr(), N, H, W, upsample_ratio, 1 if demo else 0, slot), self.h.ptr)
+
+    def pipeline_fetch(self, slot):
+        _, N = self._keep_slot[slot]
+        counts, kpts, ent, ne, kcap, ecap = self._result_buffers(N)
+        check(lib().lwp_pipeline_fetch(self.h.ptr, slot, counts.ctypes.data_as(C.POINTER(C.c_int)), kpts.ctypes.data, kcap,
+                                       ent.ctypes.data, ecap, ne.ctypes.data_as(C.POINTER(C.c_int))), self.h.ptr)
+        return self._unpack(N, counts, kpts, ent, ne)
+
     # ------------------------------------------------------------------ measurement
     def time_pipeline(self, x_cuda, iters, what=1, upsample_ratio=4, demo=True):
         """milliseconds for ``iters`` back-to-back passes (HIP events on the engine's stream)."""

@@ -415,3 +415,24 @@ def test_bf16_full_frame_batch_and_fused_post_is_exact_on_its_own_maps():
         assert np.array_equal(e.reshape(-1, 20), np.asarray(ent, dtype=np.float64).reshape(-1, 20))
         nk += total
     assert nk > 100
+
+
+def test_pipelined_streaming_gives_the_same_results_as_serial_steps():
+    """lwp_pipeline_submit/fetch (two slots, post-processing overlapped with the next network pass) == serial."""
+    from lwpose_amd import workload
+    net, _ = workload.build_net(nref=1, seed=1, device=0)
+    eng = net.engine
+    frames = [torch.from_numpy(net_input(2, 368, 656, seed=10 * i)).cuda() for i in range(5)]
+    serial = [eng.infer_poses(f, 4, demo=True) for f in frames]
+    got = []
+    for i, f in enumerate(frames):
+        eng.pipeline_submit(f, i & 1)
+        if i > 0:
+            got.append(eng.pipeline_fetch((i - 1) & 1))
+    got.append(eng.pipeline_fetch((len(frames) - 1) & 1))
+    assert len(got) == len(serial)
+    for a, b in zip(got, serial):
+        for (ea, ka, ca), (eb, kb, cb) in zip(a, b):
+            assert np.array_equal(ea, eb) and np.array_equal(ka, kb) and np.array_equal(ca, cb)
+    with pytest.raises(RuntimeError):
+        eng.pipeline_fetch(0)            # nothing pending on that slot any more
