@@ -84,8 +84,9 @@ int lwp_weights_blob_import(lwp_handle h, const void* src_device, size_t bytes);
 /* ---- network forward: replaces net(tensor_img) (demo.py:68, val.py:94;
  *      PoseEstimationWithMobileNet.forward, models/with_mobilenet.py:114-123).
  *      in: N x 3 x H x W float32 (mem).  outs: 2*(1+nref) pointers (mem, same kind as out_mem) to
- *      N x {num_heatmaps | num_pafs} x H/8 x W/8 float32 in the order [heat0, paf0, heat1, paf1, ...].
- *      H and W must be multiples of 8 (the reference pads to the stride, val.py:36-49).
+ *      N x {num_heatmaps | num_pafs} x h x w float32 in the order [heat0, paf0, heat1, paf1, ...].
+ *      Any H, W >= 8: the map size is that of three stride-2 convs, h = ((H-1)/2+1 -> ... ) (the reference pads to
+ *      the stride, val.py:36-49, but does not require it).
  *      Runs on the handle's stream and synchronises it before returning when out_mem is host. */
 int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int H, int W,
                 float* const* outs, int out_mem);
@@ -94,6 +95,12 @@ int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int H, int W,
  *      (demo.py:72,76; val.py:98,105).  src: N x C x h x w (mem);  dst: N x (h*r) x (w*r) x C (mem). */
 int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, int C, int hs, int ws, int ratio,
                  float* dst, int dst_mem);
+
+/* ---- one scale of the multi-scale average: replaces val.py:96-101 / 103-108 (x`up_ratio` cubic up-sampling of one
+ *      stage output, crop of the padding pad = [top, left, bottom, right], cubic resize to (dst_w, dst_h),
+ *      accum = accum + maps / n_scales).  maps: 1 x C x hs x ws float32 (mem); accum: dst_h x dst_w x C float32 HWC (mem). */
+int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int maps_mem, int C, int hs, int ws, int up_ratio,
+                              const int* pad, int dst_h, int dst_w, int n_scales, float* accum, int accum_mem);
 
 /* ---- extract_keypoints: replaces modules/keypoints.py:16-48 for one heat-map channel.
  *      heatmap: H x W float32 with row stride `row_stride` and pixel stride `pix_stride` (elements), host.

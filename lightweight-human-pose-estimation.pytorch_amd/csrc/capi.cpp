@@ -28,6 +28,7 @@ struct lwp_context {
     std::vector<size_t> d_outs_bytes;
     float* d_tmp = nullptr; size_t d_tmp_bytes = 0;     // generic device staging (upsample / extract / group)
     float* d_tmp2 = nullptr; size_t d_tmp2_bytes = 0;
+    float* d_tab = nullptr; size_t d_tab_bytes = 0;     // resize tables
     float* d_maps[2] = {nullptr, nullptr}; size_t d_maps_bytes[2] = {0, 0};   // bf16 path: f32 NCHW heat / PAF of the last stage
     // post-processing
     PostCaps caps;
@@ -161,6 +162,7 @@ extern "C" int lwp_destroy(lwp_handle h) {
     if (h->d_tmp) (void)hipFree(h->d_tmp);
     if (h->d_tmp2) (void)hipFree(h->d_tmp2);
     for (float* p : h->d_maps) if (p) (void)hipFree(p);
+    if (h->d_tab) (void)hipFree(h->d_tab);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -398,7 +400,7 @@ static int enqueue_forward(lwp_context* h, const float* d_in, int N, int H, int 
 
 static int check_frame_shape(lwp_context* h, int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return fail(h, LWP_ERR_ARG, "bad frame shape");
-    if (H % 8 || W % 8) return fail(h, LWP_ERR_ARG, "H and W must be multiples of the network stride (8)");
+    if (H < 8 || W < 8) return fail(h, LWP_ERR_ARG, "frame too small (H, W >= 8)");
     if (!h->weights_loaded) return fail(h, LWP_ERR_STATE, "weights not loaded (call lwp_load_weights first)");
     return LWP_OK;
 }
@@ -423,7 +425,8 @@ extern "C" int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int
     rc = stage_input(h, in, in_mem, (size_t)N * 3 * H * W * sizeof(float), &d_in);
     if (rc) return rc;
     const int nout = 2 * (1 + h->g.nref);
-    const int fh = H / 8, fw = W / 8;
+    int fh, fw;
+    level_dims(H, W, 3, &fh, &fw);               // three stride-2 stages: out = (in - 1) / 2 + 1 each
     std::vector<float*> d_outs(nout);
     for (int i = 0; i < nout; ++i) {
         if (!outs[i]) return fail(h, LWP_ERR_ARG, "null output pointer");
@@ -470,6 +473,58 @@ extern "C" int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, 
         HIP_TRY(h, hipMemcpyAsync(dst, d_dst, db, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- multi-scale accumulate
+extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int maps_mem, int C, int hs, int ws, int up_ratio,
+                                         const int* pad, int dst_h, int dst_w, int n_scales, float* accum, int accum_mem) {
+    if (!h || !maps || !pad || !accum || C <= 0 || hs <= 0 || ws <= 0 || dst_h <= 0 || dst_w <= 0 || n_scales <= 0)
+        return fail(h, LWP_ERR_ARG, "bad argument");
+    if (up_ratio != 4 && up_ratio != 8) return fail(h, LWP_ERR_ARG, "upsample ratio must be 4 or 8");
+    const int Hs = hs * up_ratio, Ws = ws * up_ratio;
+    const int ch = Hs - pad[0] - pad[2], cw = Ws - pad[1] - pad[3];
+    if (pad[0] < 0 || pad[1] < 0 || pad[2] < 0 || pad[3] < 0 || ch <= 0 || cw <= 0) return fail(h, LWP_ERR_ARG, "bad crop");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t sb = (size_t)C * hs * ws * sizeof(float), ub = sb * up_ratio * up_ratio, ab = (size_t)dst_h * dst_w * C * sizeof(float);
+    const float* d_src = maps;
+    int rc;
+    if (maps_mem == LWP_MEM_HOST) {
+        rc = ensure_dev(h, &h->d_tmp, &h->d_tmp_bytes, sb);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp, maps, sb, hipMemcpyHostToDevice, h->stream));
+        d_src = h->d_tmp;
+    }
+    rc = ensure_dev(h, &h->d_tmp2, &h->d_tmp2_bytes, ub);
+    if (rc) return rc;
+    float* d_acc = accum;
+    if (accum_mem == LWP_MEM_HOST) {
+        rc = ensure_dev(h, &h->d_maps[0], &h->d_maps_bytes[0], ab);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->d_maps[0], accum, ab, hipMemcpyHostToDevice, h->stream));
+        d_acc = h->d_maps[0];
+    }
+    std::vector<int> xi, yi;
+    std::vector<float> xw, yw;
+    build_resize_table(cw, dst_w, xi, xw);
+    build_resize_table(ch, dst_h, yi, yw);
+    const size_t tb = (xi.size() + yi.size()) * 8;
+    rc = ensure_dev(h, &h->d_tab, &h->d_tab_bytes, tb);
+    if (rc) return rc;
+    char* t = (char*)h->d_tab;
+    int* d_xi = (int*)t; t += xi.size() * 4;
+    float* d_xw = (float*)t; t += xw.size() * 4;
+    int* d_yi = (int*)t; t += yi.size() * 4;
+    float* d_yw = (float*)t;
+    HIP_TRY(h, hipMemcpyAsync(d_xi, xi.data(), xi.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_xw, xw.data(), xw.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_yi, yi.data(), yi.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_yw, yw.data(), yw.size() * 4, hipMemcpyHostToDevice, h->stream));
+    MapView v{d_src, (int64_t)C * hs * ws, (int64_t)ws, 1, (int64_t)hs * ws, hs, ws};
+    LAUNCH(h, KC_POST, launch_upsample(v, 1, C, up_ratio, h->d_tmp2, h->stream));
+    LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, d_acc, h->stream));
+    if (accum_mem == LWP_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(accum, d_acc, ab, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));      // the host tables go out of scope
     return LWP_OK;
 }
 
@@ -610,7 +665,9 @@ extern "C" int lwp_group_keypoints(lwp_handle h, const double* kpts, const int* 
 // ---------------------------------------------------------------------------------------------- fused pipeline
 static int enqueue_poses(lwp_context* h, const float* d_in, int N, int H, int W, int ratio, int demo, bool with_post) {
     const Graph& g = h->g;
-    const int fh = H / 8, fw = W / 8, cc = g.cat_channels;
+    int fh, fw;
+    level_dims(H, W, 3, &fh, &fw);
+    const int cc = g.cat_channels;
     MapView heat, paf;
     if (h->dtype == LWP_BF16) {
         // the concat buffer is bf16: the last stage's heads ALSO write f32 NCHW maps for the post-processing
@@ -648,7 +705,7 @@ static int prepare_poses(lwp_context* h, int N, int H, int W, int ratio) {
     if (rc) return rc;
     if (ratio != 4 && ratio != 8) return fail(h, LWP_ERR_ARG, "upsample ratio must be 4 or 8");
     if (h->g.NH < 18 || h->g.NP < 38) return fail(h, LWP_ERR_ARG, "pose grouping needs >= 18 heat-maps and >= 38 PAFs");
-    if ((int64_t)H / 8 * ratio > 65535 || (int64_t)W / 8 * ratio > 65535) return fail(h, LWP_ERR_ARG, "map too large");
+    if (((int64_t)H / 8 + 1) * ratio > 65535 || ((int64_t)W / 8 + 1) * ratio > 65535) return fail(h, LWP_ERR_ARG, "map too large");
     HIP_TRY(h, hipSetDevice(h->device));
     rc = ensure_activations(h, N, H, W);
     if (rc) return rc;
@@ -705,7 +762,8 @@ extern "C" int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, 
     rc = ensure_ws_obj(h, sl.ws, N, h->post_stream);
     if (rc) return rc;
     const Graph& g = h->g;
-    const int fh = H / 8, fw = W / 8;
+    int fh, fw;
+    level_dims(H, W, 3, &fh, &fw);               // three stride-2 stages: out = (in - 1) / 2 + 1 each
     const size_t hb = (size_t)N * g.NH * fh * fw * sizeof(float), pb = (size_t)N * g.NP * fh * fw * sizeof(float);
     rc = ensure_dev(h, &sl.maps[0], &sl.maps_bytes[0], hb);
     if (rc) return rc;

@@ -164,6 +164,9 @@ hipError_t launch_nms(int N, int ntypes, int Hfull, PostWorkspace& ws, hipStream
 hipError_t launch_score_pairs(const MapView& paf, int N, int ratio, int demo, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_match(int N, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_assemble(int N, PostWorkspace& ws, hipStream_t s);
+void build_resize_table(int n_src, int n_dst, std::vector<int>& idx, std::vector<float>& w);
+hipError_t launch_resize_accum(const float* src, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,
+                               const int* yi, const float* yw, int dst_h, int dst_w, float divisor, float* accum, hipStream_t s);
 hipError_t launch_threshold_inplace(float* map, int64_t n, hipStream_t s);
 hipError_t launch_nchw_from_nhwc(const float* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s);
 

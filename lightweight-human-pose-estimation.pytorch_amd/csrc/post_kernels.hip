@@ -107,6 +107,61 @@ hipError_t launch_upsample(const MapView& src, int N, int C, int ratio, float* d
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ generic cubic resize
+// cv2.resize(map, (dst_w, dst_h), INTER_CUBIC) on a cropped float32 HWC map, accumulated as avg + m / n
+// (val.py:99-101,106-108).  Per-axis tables (4 clamped source indices + 4 float32 weights per destination index) are
+// built on the host with the same arithmetic as the oracle; horizontal pass then vertical pass, left-to-right sums.
+void build_resize_table(int n_src, int n_dst, std::vector<int>& idx, std::vector<float>& w) {
+    const double inv = (double)n_dst / (double)n_src;
+    const double scale = 1.0 / inv;
+    idx.resize((size_t)n_dst * 4);
+    w.resize((size_t)n_dst * 4);
+    for (int d = 0; d < n_dst; ++d) {
+        const float fx = (float)(((double)d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(fx);
+        volatile float frac = fx - (float)s;
+        for (int k = 0; k < 4; ++k) {
+            int j = s - 1 + k;
+            idx[(size_t)d * 4 + k] = j < 0 ? 0 : (j > n_src - 1 ? n_src - 1 : j);
+        }
+        cubic_coeffs_host(frac, &w[(size_t)d * 4]);
+    }
+}
+
+__global__ void __launch_bounds__(256) resize_accum_kernel(const float* src, int Ws, int C, int crop_top, int crop_left,
+                                                            const int* xi, const float* xw, const int* yi, const float* yw,
+                                                            int dst_h, int dst_w, float divisor, float* accum) {
+    const int64_t total = (int64_t)dst_h * dst_w * C;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int x = (int)((idx / C) % dst_w);
+    const int y = (int)(idx / ((int64_t)C * dst_w));
+    int64_t xo[4];
+    float wx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { xo[j] = (int64_t)(crop_left + xi[x * 4 + j]) * C + c; wx[j] = xw[x * 4 + j]; }
+    float o = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* row = src + (int64_t)(crop_top + yi[y * 4 + k]) * Ws * C;
+        float a = __fmul_rn(row[xo[0]], wx[0]);
+        a = __fadd_rn(a, __fmul_rn(row[xo[1]], wx[1]));
+        a = __fadd_rn(a, __fmul_rn(row[xo[2]], wx[2]));
+        a = __fadd_rn(a, __fmul_rn(row[xo[3]], wx[3]));
+        const float t = __fmul_rn(a, yw[y * 4 + k]);
+        o = k == 0 ? t : __fadd_rn(o, t);
+    }
+    accum[idx] = __fadd_rn(accum[idx], __fdiv_rn(o, divisor));
+}
+hipError_t launch_resize_accum(const float* src, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,
+                               const int* yi, const float* yw, int dst_h, int dst_w, float divisor, float* accum, hipStream_t s) {
+    const int64_t total = (int64_t)dst_h * dst_w * C;
+    hipLaunchKernelGGL(resize_accum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, Ws, C, crop_top, crop_left,
+                       xi, xw, yi, yw, dst_h, dst_w, divisor, accum);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) threshold_kernel(float* m, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && m[i] < 0.1f) m[i] = 0.f;     // keypoints.py:17 (NaN stays NaN)

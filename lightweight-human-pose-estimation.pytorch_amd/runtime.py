@@ -79,7 +79,10 @@ class Engine(object):
         on_dev = t.is_cuda
         if on_dev and t.device.index != self.device_id:
             raise ValueError("input is on cuda:%d but the engine lives on cuda:%d" % (t.device.index, self.device_id))
-        shapes = [(N, self.NP if i % 2 else self.NH, H // 8, W // 8) for i in range(2 * (1 + self.nref))]
+        fh, fw = H, W
+        for _ in range(3):                       # three stride-2 stages: out = (in - 1) // 2 + 1
+            fh, fw = (fh - 1) // 2 + 1, (fw - 1) // 2 + 1
+        shapes = [(N, self.NP if i % 2 else self.NH, fh, fw) for i in range(2 * (1 + self.nref))]
         outs = [torch.empty(s, dtype=torch.float32, device=t.device) for s in shapes]
         ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
         if on_dev:
@@ -107,6 +110,30 @@ class Engine(object):
         out = np.empty((N, h * ratio, w * ratio, Cc), dtype=np.float32)
         check(lib().lwp_upsample(self.h.ptr, ptr, mem, N, Cc, h, w, ratio, out.ctypes.data, MEM_HOST), self.h.ptr)
         return out
+
+    def multiscale_accumulate(self, accum, maps, up_ratio, pad, n_scales):
+        """accum (H,W,C) float32 [numpy or cuda tensor, updated in place] += resize(crop(upsample(maps))) / n_scales
+        (val.py:96-101).  maps: (1,C,h,w) or (C,h,w) float32 numpy / cuda tensor."""
+        def ptr_mem(a):
+            if getattr(a, "is_cuda", False):
+                return a.data_ptr(), MEM_DEVICE
+            return a.ctypes.data, MEM_HOST
+        if getattr(maps, "is_cuda", False):
+            maps = maps.detach().contiguous()
+            _torch().cuda.current_stream(maps.device).synchronize()
+        else:
+            maps = np.ascontiguousarray(maps, dtype=np.float32)
+        shp = tuple(maps.shape)[-3:]
+        H, W, Cc = tuple(accum.shape)
+        if Cc != shp[0]:
+            raise ValueError("channel mismatch")
+        if not getattr(accum, "is_cuda", False) and (accum.dtype != np.float32 or not accum.flags.c_contiguous):
+            raise TypeError("accum must be a C-contiguous float32 array")
+        mp, mm = ptr_mem(maps)
+        ap, am = ptr_mem(accum)
+        padv = (C.c_int * 4)(*[int(v) for v in pad])
+        check(lib().lwp_multiscale_accumulate(self.h.ptr, mp, mm, shp[0], shp[1], shp[2], up_ratio, padv, H, W, n_scales, ap, am), self.h.ptr)
+        return accum
 
     def extract_keypoints(self, heatmap):
         """In-place threshold of ``heatmap`` (2-D float32 view) and key-point list [(x, y, score)]."""

@@ -64,3 +64,46 @@ def resize_cubic_u8(img, fx, fy):
     t = sum(src[:, xi[:, k]] * xw[None, :, k, None] for k in range(4))
     o = sum(t[yi[:, k]] * yw[:, k, None, None] for k in range(4))
     return np.clip((o + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+
+
+def resize_cubic_float(img, ratio):
+    """cv2.resize(img, (0,0), fx=ratio, fy=ratio, interpolation=cv2.INTER_CUBIC) for the float64 normalised image
+    (val.py:89): destination size round(src*ratio), scale 1/ratio, float32 coefficients, float64 sums."""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    h, w = img.shape[:2]
+    dw, dh = int(round(w * ratio)), int(round(h * ratio))
+
+    def tables(n_src, n_dst):
+        d = np.arange(n_dst)
+        f = ((d + 0.5) * (1.0 / ratio) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        frac = f - s.astype(np.float32)
+        idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+        return idx, np.stack([_cubic_coeffs_f32(t) for t in frac]).astype(np.float64)
+    xi, xw = tables(w, dw)
+    yi, yw = tables(h, dh)
+    t = sum(img[:, xi[:, k]] * xw[None, :, k, None] for k in range(4))
+    return sum(t[yi[:, k]] * yw[:, k, None, None] for k in range(4))
+
+
+def infer(net, img, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
+    """Drop-in for the reference's multi-scale ``val.infer`` (val.py:81-110): returns (avg_heatmaps HxWx19,
+    avg_pafs HxWx38) float32 at the original image size.  The image-side resize/pad stay on the host like the
+    reference; the network and the per-scale up-sample / crop / resize / average run on the GPU."""
+    import torch
+    normed_img = normalize(img, img_mean, img_scale)
+    height, width, _ = normed_img.shape
+    scales_ratios = [scale * base_height / float(height) for scale in scales]
+    eng = net.engine
+    dev = torch.device("cuda", eng.device_id)
+    avg_heatmaps = torch.zeros((height, width, eng.NH), dtype=torch.float32, device=dev)
+    avg_pafs = torch.zeros((height, width, eng.NP), dtype=torch.float32, device=dev)
+    for ratio in scales_ratios:
+        scaled_img = resize_cubic_float(normed_img, ratio)
+        min_dims = [base_height, max(scaled_img.shape[1], base_height)]
+        padded_img, pad = pad_width(scaled_img, stride, pad_value, min_dims)
+        x = torch.from_numpy(np.ascontiguousarray(padded_img.transpose(2, 0, 1)[None], dtype=np.float32)).to(dev)
+        stages_output = net(x)
+        eng.multiscale_accumulate(avg_heatmaps, stages_output[-2], stride, pad, len(scales_ratios))
+        eng.multiscale_accumulate(avg_pafs, stages_output[-1], stride, pad, len(scales_ratios))
+    return avg_heatmaps.cpu().numpy(), avg_pafs.cpu().numpy()

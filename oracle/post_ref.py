@@ -66,6 +66,71 @@ def upsample_cubic(img, ratio):
     return o
 
 
+def resize_tables(n_src, n_dst):
+    """OpenCV generic cubic resize along one axis for an explicit destination size: per destination index 4
+    clamped source indices and 4 float32 weights (inv_scale = dst/src, scale = 1/inv_scale, resize.cpp)."""
+    inv = float(n_dst) / float(n_src)
+    scale = 1.0 / inv
+    d = np.arange(n_dst)
+    fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(fx).astype(np.int64)
+    frac = fx - s.astype(np.float32)
+    idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+    w = np.stack([cubic_coeffs(t) for t in frac]).astype(np.float32)
+    return idx, w
+
+
+def resize_cubic(img, dst_w, dst_h):
+    """cv2.resize(img, (dst_w, dst_h), interpolation=cv2.INTER_CUBIC) for float32 (h, w, C) maps (val.py:100,107):
+    horizontal pass then vertical pass, left-to-right float32 sums."""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    h, w, _ = img.shape
+    xi, xw = resize_tables(w, dst_w)
+    yi, yw = resize_tables(h, dst_h)
+    t = img[:, xi[:, 0]] * xw[None, :, 0, None]
+    for k in (1, 2, 3):
+        t = t + img[:, xi[:, k]] * xw[None, :, k, None]
+    o = t[yi[:, 0]] * yw[:, 0, None, None]
+    for k in (1, 2, 3):
+        o = o + t[yi[:, k]] * yw[:, k, None, None]
+    return o
+
+
+def resize_cubic_f64_by_ratio(img, ratio):
+    """cv2.resize(img, (0,0), fx=ratio, fy=ratio, INTER_CUBIC) for a float64 image (val.py:89: the normalised image is
+    float64): destination size round(src*ratio), scale = 1/ratio, float32 coefficients, float64 accumulation."""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    h, w, _ = img.shape
+    dw, dh = int(round(w * ratio)), int(round(h * ratio))
+
+    def tables(n_src, n_dst):
+        scale = 1.0 / ratio
+        d = np.arange(n_dst)
+        fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(fx).astype(np.int64)
+        frac = fx - s.astype(np.float32)
+        idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+        return idx, np.stack([cubic_coeffs(t) for t in frac]).astype(np.float64)
+    xi, xw = tables(w, dw)
+    yi, yw = tables(h, dh)
+    t = img[:, xi[:, 0]] * xw[None, :, 0, None]
+    for k in (1, 2, 3):
+        t = t + img[:, xi[:, k]] * xw[None, :, k, None]
+    o = t[yi[:, 0]] * yw[:, 0, None, None]
+    for k in (1, 2, 3):
+        o = o + t[yi[:, k]] * yw[:, k, None, None]
+    return o
+
+
+def multiscale_accumulate(avg, maps_chw, stride, pad, width, height, n_scales):
+    """One scale of val.infer's inner loop for one map set (val.py:96-101): x`stride` cubic up-sampling, crop of the
+    padding, cubic resize to (width, height), avg + maps / n_scales."""
+    m = upsample_cubic(np.ascontiguousarray(maps_chw, dtype=np.float32).transpose(1, 2, 0), stride)
+    m = m[pad[0]:m.shape[0] - pad[2], pad[1]:m.shape[1] - pad[3], :]
+    m = resize_cubic(m, width, height)
+    return avg + m / n_scales
+
+
 # ----------------------------------------------------------------------------- extract
 def extract_keypoints(heatmap, all_keypoints, total_keypoint_num):
     heatmap[heatmap < 0.1] = 0          # in place, like the reference (keypoints.py:17)

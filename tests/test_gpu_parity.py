@@ -147,6 +147,20 @@ def test_net_full_368x656_golden_and_oracle():
         assert np.abs(o - ref[i].numpy()).max() <= NET_TOL
 
 
+def test_net_odd_sizes_not_multiple_of_stride():
+    """The reference does not require H, W to be multiples of 8 (val.infer at scale 1.5 of a 184-high base): the map
+    sizes follow the conv arithmetic."""
+    net, sd = get_net(1, 1)
+    x = net_input(2, 92, 150, seed=400)[:, :, :91, :149].copy()
+    outs = net(x)
+    ref = net_ref.forward(sd, torch.from_numpy(x), 1)
+    for o, r in zip(outs, ref):
+        assert o.shape == tuple(r.shape)
+        assert np.abs(o - r.numpy()).max() <= NET_TOL
+    res = net.engine.infer_poses(x, 4, demo=True)
+    assert len(res) == 2
+
+
 def test_net_cuda_tensor_in_out_and_batch_consistency():
     net, _ = get_net(1, 1)
     x = net_input(4, 128, 192, seed=300)
@@ -181,7 +195,9 @@ def test_load_state_semantics_match_reference_golden(capsys):
 def test_errors_are_loud(eng):
     net = PoseEstimationWithMobileNet(1)
     with pytest.raises(ValueError):
-        net.cuda()(np.zeros((1, 3, 60, 64), np.float32))        # H not a multiple of the stride
+        net.cuda()(np.zeros((1, 4, 64, 64), np.float32))        # not 3 input channels
+    with pytest.raises(ValueError):
+        net.cuda()(np.zeros((1, 3, 4, 64), np.float32))         # frame too small
     with pytest.raises(RuntimeError):
         net.cpu()
     with pytest.raises(TypeError):
@@ -436,3 +452,32 @@ def test_pipelined_streaming_gives_the_same_results_as_serial_steps():
             assert np.array_equal(ea, eb) and np.array_equal(ka, kb) and np.array_equal(ca, cb)
     with pytest.raises(RuntimeError):
         eng.pipeline_fetch(0)            # nothing pending on that slot any more
+
+
+# ------------------------------------------------------------------------------------------ multi-scale (config 4)
+def test_multiscale_accumulate_bit_exact(eng):
+    """lwp_multiscale_accumulate == oracle (x8 up-sample, crop, cubic resize to the image size, avg + m / n)."""
+    heat, paf, _ = synth.make_pose_maps(3, 23, 46, 21)
+    for maps, pad, (dh, dw) in ((heat, [0, 3, 0, 3], (150, 301)), (paf, [92, 20, 92, 20], (184, 328)), (heat, [0, 0, 0, 0], (184, 368))):
+        if pad[0] * 2 >= maps.shape[1] * 8 or pad[1] * 2 >= maps.shape[2] * 8:
+            pad = [4, 8, 4, 8]
+        acc0 = (synth.uniform((dh, dw, maps.shape[0]), 77) - 0.5).astype(np.float32)
+        ref = post_ref.multiscale_accumulate(acc0.copy(), maps, 8, pad, dw, dh, 3)
+        got = eng.multiscale_accumulate(np.ascontiguousarray(acc0.copy()), maps[None], 8, pad, 3)
+        assert got.dtype == np.float32 and got.shape == ref.shape
+        assert np.array_equal(got, ref)
+        acc_t = torch.from_numpy(acc0.copy()).cuda()
+        eng.multiscale_accumulate(acc_t, torch.from_numpy(maps[None].copy()).cuda(), 8, pad, 3)
+        assert np.array_equal(acc_t.cpu().numpy(), ref)
+
+
+def test_val_infer_multiscale_matches_oracle():
+    """Drop-in val.infer (scales 0.5/1.0/1.5, base height 368 -> here a reduced 184-high frame) vs the oracle driver."""
+    from lwpose_amd.val import infer
+    from oracle import preproc_ref
+    net, sd = get_net(3, 1)
+    img = synth.make_frames(1, 92, 120, seed0=5)[0]
+    got_h, got_p = infer(net, img, [0.5, 1.0, 1.5], 184, 8)
+    ref_h, ref_p = preproc_ref.infer(sd, 3, img, [0.5, 1.0, 1.5], 184, 8)
+    assert got_h.shape == (92, 120, 19) and got_p.shape == (92, 120, 38)
+    assert np.abs(got_h - ref_h).max() <= 2e-3 and np.abs(got_p - ref_p).max() <= 2e-3

@@ -167,3 +167,15 @@ def test_upsample_matches_torch_bicubic():
     for fr in (0.125, 0.375, 0.625, 0.875):
         c = post_ref.cubic_coeffs(fr)
         assert abs(float(c.astype(np.float64).sum()) - 1.0) < 1e-6
+
+
+def test_generic_resize_matches_integer_ratio_and_torch():
+    heat, _, _ = synth.make_pose_maps(3, 23, 41, 11)
+    hwc = heat.transpose(1, 2, 0)
+    assert np.array_equal(post_ref.resize_cubic(hwc, 41 * 4, 23 * 4), post_ref.upsample_cubic(hwc, 4))
+    for (dw, dh) in ((100, 57), (30, 17), (41, 23)):
+        got = post_ref.resize_cubic(hwc, dw, dh)
+        t = torch.nn.functional.interpolate(torch.from_numpy(heat)[None], size=(dh, dw), mode="bicubic",
+                                            align_corners=False)[0].numpy().transpose(1, 2, 0)
+        assert np.abs(got - t).max() < 3e-6
+    assert np.array_equal(post_ref.resize_cubic(hwc, 41, 23), hwc)          # identity size -> identity
