@@ -1,103 +1,111 @@
-"""Pose container, similarity and id tracking (reference: modules/pose.py:8-118), without OpenCV:
-``cv2.boundingRect`` of integer points is (min_x, min_y, max_x-min_x+1, max_y-min_y+1)."""
+"""Pose container, OKS-like similarity and id tracking with the reference's public surface
+(modules/pose.py:8-118: Pose.num_kpts / kpt_names / sigmas / vars / last_id, Pose(keypoints, confidence),
+.bbox, .id, .filters, get_bbox, update_id, draw, get_similarity, track_poses), without OpenCV.
+
+cv2.boundingRect of integer points is (min_x, min_y, max_x - min_x + 1, max_y - min_y + 1); the similarity of all
+pose pairs is computed as one NumPy expression and ids are assigned in descending-confidence order.
+"""
 import numpy as np
 
 from .keypoints import BODY_PARTS_KPT_IDS, BODY_PARTS_PAF_IDS
 from .one_euro_filter import OneEuroFilter
+
+_SIGMAS = np.array([.26, .79, .79, .72, .62, .79, .72, .62, 1.07, .87, .89, 1.07, .87, .89, .25, .25, .35, .35],
+                   dtype=np.float32) / 10.0
 
 
 class Pose:
     num_kpts = 18
     kpt_names = ['nose', 'neck', 'r_sho', 'r_elb', 'r_wri', 'l_sho', 'l_elb', 'l_wri', 'r_hip', 'r_knee', 'r_ank',
                  'l_hip', 'l_knee', 'l_ank', 'r_eye', 'l_eye', 'r_ear', 'l_ear']
-    sigmas = np.array([.26, .79, .79, .72, .62, .79, .72, .62, 1.07, .87, .89, 1.07, .87, .89, .25, .25, .35, .35],
-                      dtype=np.float32) / 10.0
-    vars = (sigmas * 2) ** 2
+    sigmas = _SIGMAS
+    vars = (_SIGMAS * 2) ** 2
     last_id = -1
     color = [0, 224, 255]
 
     def __init__(self, keypoints, confidence):
-        self.keypoints = keypoints
+        self.keypoints = keypoints                      # (18, 2) int32, -1 = not found
         self.confidence = confidence
-        self.bbox = Pose.get_bbox(self.keypoints)
         self.id = None
-        self.filters = [[OneEuroFilter(), OneEuroFilter()] for _ in range(Pose.num_kpts)]
+        self.filters = [[OneEuroFilter(), OneEuroFilter()] for _ in range(self.num_kpts)]
+        self.bbox = self.get_bbox(keypoints)
 
     @staticmethod
     def get_bbox(keypoints):
-        found = keypoints[keypoints[:, 0] != -1]
-        if len(found) == 0:
+        present = keypoints[:, 0] != -1
+        if not present.any():
             return (0, 0, 0, 0)
-        x0, y0 = int(found[:, 0].min()), int(found[:, 1].min())
-        return (x0, y0, int(found[:, 0].max()) - x0 + 1, int(found[:, 1].max()) - y0 + 1)
+        lo = keypoints[present].min(axis=0)
+        hi = keypoints[present].max(axis=0)
+        return (int(lo[0]), int(lo[1]), int(hi[0] - lo[0] + 1), int(hi[1] - lo[1] + 1))
 
     def update_id(self, id=None):
-        self.id = id
-        if self.id is None:
-            self.id = Pose.last_id + 1
+        if id is None:
             Pose.last_id += 1
+            id = Pose.last_id
+        self.id = id
 
     def draw(self, img):
-        """Minimal rasteriser (filled 3-px discs and 2-px segments) — OpenCV is not a dependency here."""
+        """Rasterises joints (radius 3) and limbs (width ~2) straight into ``img`` (H, W, 3)."""
         assert self.keypoints.shape == (Pose.num_kpts, 2)
         h, w = img.shape[:2]
 
-        def disc(cx, cy, r=3):
-            y0, y1, x0, x1 = max(cy - r, 0), min(cy + r + 1, h), max(cx - r, 0), min(cx + r + 1, w)
-            if y0 >= y1 or x0 >= x1:
+        def stamp(cx, cy, r):
+            ys = slice(max(cy - r, 0), min(cy + r + 1, h))
+            xs = slice(max(cx - r, 0), min(cx + r + 1, w))
+            if ys.start >= ys.stop or xs.start >= xs.stop:
                 return
-            yy, xx = np.mgrid[y0:y1, x0:x1]
-            img[y0:y1, x0:x1][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = Pose.color
+            gy, gx = np.ogrid[ys, xs]
+            img[ys, xs][(gy - cy) ** 2 + (gx - cx) ** 2 <= r * r] = Pose.color
 
-        for part_id in range(len(BODY_PARTS_PAF_IDS) - 2):
-            a, b = BODY_PARTS_KPT_IDS[part_id]
-            has_a, has_b = self.keypoints[a, 0] != -1, self.keypoints[b, 0] != -1
-            if has_a:
-                disc(int(self.keypoints[a, 0]), int(self.keypoints[a, 1]))
-            if has_b:
-                disc(int(self.keypoints[b, 0]), int(self.keypoints[b, 1]))
-            if has_a and has_b:
-                n = int(max(abs(self.keypoints[a] - self.keypoints[b]).max(), 1))
-                for t in np.linspace(0.0, 1.0, n + 1):
-                    p = self.keypoints[a] + t * (self.keypoints[b] - self.keypoints[a])
-                    disc(int(p[0]), int(p[1]), 1)
+        for a, b in BODY_PARTS_KPT_IDS[:len(BODY_PARTS_PAF_IDS) - 2]:
+            pa, pb = self.keypoints[a], self.keypoints[b]
+            if pa[0] != -1:
+                stamp(int(pa[0]), int(pa[1]), 3)
+            if pb[0] != -1:
+                stamp(int(pb[0]), int(pb[1]), 3)
+            if pa[0] != -1 and pb[0] != -1:
+                steps = int(max(np.abs(pb - pa).max(), 1))
+                for s in range(steps + 1):
+                    q = pa + (pb - pa) * (s / steps)
+                    stamp(int(q[0]), int(q[1]), 1)
+
+
+def _similar_keypoints(a, b, threshold=0.5):
+    """Number of key-points present in both poses whose OKS-like similarity exceeds ``threshold``."""
+    both = (a.keypoints[:, 0] != -1) & (b.keypoints[:, 0] != -1)
+    if not both.any():
+        return 0
+    d2 = ((a.keypoints[both] - b.keypoints[both]) ** 2).sum(axis=1)
+    area = max(a.bbox[2] * a.bbox[3], b.bbox[2] * b.bbox[3])
+    sim = np.exp(-d2 / (2 * (area + np.spacing(1)) * Pose.vars[both]))
+    return int((sim > threshold).sum())
 
 
 def get_similarity(a, b, threshold=0.5):
-    num_similar_kpt = 0
-    for kpt_id in range(Pose.num_kpts):
-        if a.keypoints[kpt_id, 0] != -1 and b.keypoints[kpt_id, 0] != -1:
-            distance = np.sum((a.keypoints[kpt_id] - b.keypoints[kpt_id]) ** 2)
-            area = max(a.bbox[2] * a.bbox[3], b.bbox[2] * b.bbox[3])
-            similarity = np.exp(-distance / (2 * (area + np.spacing(1)) * Pose.vars[kpt_id]))
-            if similarity > threshold:
-                num_similar_kpt += 1
-    return num_similar_kpt
+    return _similar_keypoints(a, b, threshold)
 
 
 def track_poses(previous_poses, current_poses, threshold=3, smooth=False):
-    """Propagate ids from the previous frame (>= ``threshold`` similar key-points), optionally smoothing."""
-    current_poses = sorted(current_poses, key=lambda pose: pose.confidence, reverse=True)
-    free = np.ones(len(previous_poses), dtype=np.int32)
-    for cur in current_poses:
-        best_idx, best_pose_id, best_sim = None, None, 0
-        for idx, prev in enumerate(previous_poses):
-            if not free[idx]:
+    """Give every current pose the id of the most similar still-unclaimed previous pose (at least ``threshold``
+    similar key-points), most confident poses first; unmatched poses get fresh ids.  With ``smooth`` the matched
+    key-points continue the previous pose's 1-Euro filters."""
+    claimed = [False] * len(previous_poses)
+    for cur in sorted(current_poses, key=lambda p: p.confidence, reverse=True):
+        scores = [0 if claimed[i] else _similar_keypoints(cur, prev) for i, prev in enumerate(previous_poses)]
+        best = int(np.argmax(scores)) if scores else -1          # first maximum, like a strict '>' scan
+        matched = best >= 0 and scores[best] >= threshold and scores[best] > 0
+        if matched:
+            claimed[best] = True
+        cur.update_id(previous_poses[best].id if matched else None)
+        if not smooth:
+            continue
+        for k in range(Pose.num_kpts):
+            if cur.keypoints[k, 0] == -1:
                 continue
-            sim = get_similarity(cur, prev)
-            if sim > best_sim:
-                best_sim, best_pose_id, best_idx = sim, prev.id, idx
-        if best_sim >= threshold:
-            free[best_idx] = 0
-        else:
-            best_pose_id = None
-        cur.update_id(best_pose_id)
-        if smooth:
-            for k in range(Pose.num_kpts):
-                if cur.keypoints[k, 0] == -1:
-                    continue
-                if best_pose_id is not None and previous_poses[best_idx].keypoints[k, 0] != -1:
-                    cur.filters[k] = previous_poses[best_idx].filters[k]
-                cur.keypoints[k, 0] = cur.filters[k][0](cur.keypoints[k, 0])
-                cur.keypoints[k, 1] = cur.filters[k][1](cur.keypoints[k, 1])
-            cur.bbox = Pose.get_bbox(cur.keypoints)
+            if matched and previous_poses[best].keypoints[k, 0] != -1:
+                cur.filters[k] = previous_poses[best].filters[k]
+            fx, fy = cur.filters[k]
+            cur.keypoints[k, 0] = fx(cur.keypoints[k, 0])
+            cur.keypoints[k, 1] = fy(cur.keypoints[k, 1])
+        cur.bbox = Pose.get_bbox(cur.keypoints)
