@@ -43,7 +43,7 @@ def layer_work(layers, N, H, W, elt_bytes=4):
             byt = (N * hi * wi * 3 + m_out * 32) * 4 + 27 * 32 * 4
         elif l["kind"] == 3:       # fused depthwise -> pointwise: charged to the (MFMA-bound) 1x1 class with both ops' FLOPs
             k = "pointwise_1x1"
-            flops = 2.0 * m_out * (9 * l["cin"] + l["cin"] * l["cout"])
+            flops = 2.0 * m_out * l["macs_per_pixel"]
             byt = (N * hi * wi * l["cin"] + m_out * l["cout"] + 9 * l["cin"] + l["cin"] * l["cout"]) * elt_bytes
         elif l["kind"] == 1:
             k = "depthwise"
@@ -51,7 +51,7 @@ def layer_work(layers, N, H, W, elt_bytes=4):
             byt = (N * hi * wi * l["cin"] + m_out * l["cout"] + 9 * l["cin"]) * elt_bytes
         else:
             k = "pointwise_1x1" if l["ksize"] == 1 else "dense_3x3"
-            flops = 2.0 * m_out * l["cin"] * l["cout"] * l["ksize"] ** 2
+            flops = 2.0 * m_out * l["macs_per_pixel"]        # merged heads: zero blocks are not counted
             byt = (m_out * (l["cin"] + l["cout"]) + l["cin"] * l["cout"] * l["ksize"] ** 2) * elt_bytes
         acc[k][0] += flops
         acc[k][1] += byt

@@ -174,7 +174,7 @@ int lwp_synchronize(lwp_handle h);
  *      N x cout x h x w; dims are returned in out_dims[4]. */
 int lwp_layer_count(lwp_handle h);
 int lwp_layer_info(lwp_handle h, int layer_index, char* name, int name_cap, int* kind, int* cin, int* cout,
-                   int* ksize, int* stride, int* dilation);
+                   int* ksize, int* stride, int* dilation, int64_t* macs_per_pixel /* algorithmic multiply-adds */);
 /* average device time (ms) of `iters` back-to-back launches of one layer on the current buffers */
 int lwp_debug_time_layer(lwp_handle h, int layer_index, int N, int H, int W, int iters, float* ms_avg);
 int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int H, int W, int layer_index,

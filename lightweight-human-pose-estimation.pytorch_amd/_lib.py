@@ -66,7 +66,7 @@ def lib():
     L.lwp_pipeline_fetch.argtypes = [vp, C.c_int, ip, vp, C.c_int, vp, C.c_int, ip]
     L.lwp_multiscale_accumulate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     L.lwp_layer_count.argtypes = [vp]
-    L.lwp_layer_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int] + [ip] * 6
+    L.lwp_layer_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int] + [ip] * 6 + [i64p]
     L.lwp_debug_layer_output.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, ip]
     for name in EXPORTS:
         if name not in ("lwp_last_error",):

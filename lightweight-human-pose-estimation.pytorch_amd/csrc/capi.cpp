@@ -124,7 +124,8 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
     h->dtype = dtype;
     {
         const char* fe = getenv("LWP_FUSE_DWPW");   // "0" keeps depthwise and pointwise as separate launches (A/B, tests)
-        h->g = build_graph(nref, C, NH, NP, !(fe && fe[0] == '0'), dtype);
+        const char* me = getenv("LWP_MERGE_HEADS");   // "0": separate heat / PAF head GEMMs (A/B)
+        h->g = build_graph(nref, C, NH, NP, !(fe && fe[0] == '0'), dtype, !(me && me[0] == '0'));
     }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
@@ -378,6 +379,8 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
         p.out = dst; p.out_ld = l.dst.ld;
         p.res = l.res.buf >= 0 ? buf_at(h, l.res) : nullptr; p.res_ld = l.res.ld;
         p.out_nchw = (l.out_index >= 0 && d_outs_nchw) ? d_outs_nchw[l.out_index] : nullptr;
+        p.out_nchw2 = (l.out_index2 >= 0 && d_outs_nchw) ? d_outs_nchw[l.out_index2] : nullptr;
+        p.out_split = l.out_split;
         p.zeros = h->d_zeros;
         p.N = N; p.H = dh; p.W = dw;
         p.cin_pad = l.cin_pad; p.cout = l.cout; p.cout_pad = l.cout_pad; p.ks = l.ks; p.dil = l.dil; p.act = l.act;
@@ -849,7 +852,7 @@ extern "C" int lwp_poses_from_maps(lwp_handle h, const float* heat, const float*
 extern "C" int lwp_layer_count(lwp_handle h) { return h ? (int)h->g.layers.size() : LWP_ERR_ARG; }
 
 extern "C" int lwp_layer_info(lwp_handle h, int idx, char* name, int name_cap, int* kind, int* cin, int* cout, int* ks,
-                              int* stride, int* dil) {
+                              int* stride, int* dil, int64_t* macs_per_pixel) {
     if (!h || idx < 0 || idx >= (int)h->g.layers.size() || !name) return fail(h, LWP_ERR_ARG, "bad argument");
     const Layer& l = h->g.layers[idx];
     if ((int)l.name.size() + 1 > name_cap) return fail(h, LWP_ERR_ARG, "name buffer too small");
@@ -860,6 +863,7 @@ extern "C" int lwp_layer_info(lwp_handle h, int idx, char* name, int name_cap, i
     if (ks) *ks = l.ks;
     if (stride) *stride = l.stride;
     if (dil) *dil = l.dil;
+    if (macs_per_pixel) *macs_per_pixel = l.macs_per_pixel;
     return LWP_OK;
 }
 

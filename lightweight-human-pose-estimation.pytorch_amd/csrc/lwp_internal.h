@@ -29,6 +29,11 @@ struct BufRef {      // a channel window of an NHWC activation buffer
     int ld = 0;      // row stride (channels per pixel) the layer addresses the buffer with
 };
 
+struct WBlock {              // one source conv of a merged 1x1 layer: W[out_off + o][in_off + i] = conv.weight[o][i]
+    std::string conv_key;
+    int out_off, in_off, cout, cin;
+};
+
 struct Layer {
     int kind = L_GEMM;
     std::string name;          // e.g. "model.3.pw"
@@ -38,6 +43,9 @@ struct Layer {
     int cin = 0, cout = 0, ks = 1, stride = 1, dil = 1, act = ACT_NONE;
     BufRef src, dst, res;      // res.buf < 0: no residual
     int out_index = -1;        // >= 0: this layer also produces stage output #out_index (NCHW)
+    int out_index2 = -1, out_split = 0;   // merged heads: channels >= out_split belong to stage output #out_index2
+    std::vector<WBlock> blocks;           // non-empty: weight matrix assembled from these convs (zeros elsewhere)
+    int64_t macs_per_pixel = 0;           // algorithmic multiply-adds per output pixel (zero blocks not counted)
     // packed weights (float offsets into the blob)
     size_t w_off = 0, b_off = 0;
     int cin_pad = 0, cout_pad = 0;
@@ -61,7 +69,7 @@ struct Graph {
     int cat_channels = 0;
     int dtype = LWP_F32;       // storage / MFMA dtype of the conv stack (weights packed accordingly)
 };
-Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype);
+Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype, bool merge_heads = true);
 
 struct HostTensor {
     const void* ptr;
@@ -93,7 +101,9 @@ struct GemmParams {
     const float* bias;               // [cout_pad]
     float* out; int out_ld;
     const float* res; int res_ld;    // may be null
-    float* out_nchw;                 // may be null: N x cout x H x W
+    float* out_nchw;                 // may be null: N x cout x H x W  (x out_split channels when out_split > 0)
+    float* out_nchw2 = nullptr;      // merged heads: channels >= out_split, N x (cout - out_split) x H x W
+    int out_split = 0;
     const float* zeros;              // >= 16 bytes of zeros (source of out-of-image taps)
     int N, H, W, cin_pad, cout, cout_pad, ks, dil, act;
 };

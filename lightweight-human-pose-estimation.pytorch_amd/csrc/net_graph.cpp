@@ -106,7 +106,7 @@ struct Builder {
 };
 }  // namespace
 
-Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype) {
+Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype, bool merge_heads) {
     Builder b;
     Graph& g = b.g;
     g.nref = nref; g.C = C; g.NH = NH; g.NP = NP; g.dtype = dtype;
@@ -119,6 +119,7 @@ Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype) {
     int S0 = b.new_buf(3, C), S1 = b.new_buf(3, C), S2 = b.new_buf(3, C);
     int catc = round_up(C + NH + NP, 64);
     int CAT = b.new_buf(3, catc);
+    const int H2 = b.new_buf(3, 1024 > 2 * C ? 1024 : 2 * C);   // [heat hidden | paf hidden] of the merged head GEMMs
     g.cat_buf = CAT; g.cat_channels = catc;
 
     b.add(L_STEM, "model.0", "model.0.0", "model.0.1", false, 3, 32, 3, 2, 1, ACT_RELU, Builder::ref(-1, 3), Builder::ref(s1, 32));
@@ -171,10 +172,26 @@ Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype) {
     b.add(L_GEMM, "initial_stage.trunk.0", "initial_stage.trunk.0.0", "", true, C, C, 3, 1, 1, ACT_RELU, Builder::ref(CAT, catc, 0), Builder::ref(S0, C));
     b.add(L_GEMM, "initial_stage.trunk.1", "initial_stage.trunk.1.0", "", true, C, C, 3, 1, 1, ACT_RELU, Builder::ref(S0, C), Builder::ref(S1, C));
     b.add(L_GEMM, "initial_stage.trunk.2", "initial_stage.trunk.2.0", "", true, C, C, 3, 1, 1, ACT_RELU, Builder::ref(S1, C), Builder::ref(S0, C));
-    b.add(L_GEMM, "initial_stage.heatmaps.0", "initial_stage.heatmaps.0.0", "", true, C, 512, 1, 1, 1, ACT_RELU, Builder::ref(S0, C), Builder::ref(X, 512));
-    b.add(L_GEMM, "initial_stage.pafs.0", "initial_stage.pafs.0.0", "", true, C, 512, 1, 1, 1, ACT_RELU, Builder::ref(S0, C), Builder::ref(Y, 512));
-    b.add(L_GEMM, "initial_stage.heatmaps.1", "initial_stage.heatmaps.1.0", "", true, 512, NH, 1, 1, 1, ACT_NONE, Builder::ref(X, 512), Builder::ref(CAT, catc, C)).out_index = 0;
-    b.add(L_GEMM, "initial_stage.pafs.1", "initial_stage.pafs.1.0", "", true, 512, NP, 1, 1, 1, ACT_NONE, Builder::ref(Y, 512), Builder::ref(CAT, catc, C + NH)).out_index = 1;
+    // stage heads (with_mobilenet.py:32-45): heatmaps.0 and pafs.0 read the same input -> ONE GEMM with concatenated
+    // outputs; heatmaps.1 and pafs.1 -> ONE block-diagonal GEMM writing [heat | paf] into the concat buffer and both
+    // NCHW stage outputs.  4 launches per stage become 2 (at batch 1 every launch costs a ~6-10 us floor).
+    auto add_heads = [&](const std::string& p, int in_buf, int hidden, int out0) {
+        if (!merge_heads) {
+            b.add(L_GEMM, p + ".heatmaps.0", p + ".heatmaps.0.0", "", true, C, hidden, 1, 1, 1, ACT_RELU, Builder::ref(in_buf, C), Builder::ref(X, hidden));
+            b.add(L_GEMM, p + ".pafs.0", p + ".pafs.0.0", "", true, C, hidden, 1, 1, 1, ACT_RELU, Builder::ref(in_buf, C), Builder::ref(Y, hidden));
+            b.add(L_GEMM, p + ".heatmaps.1", p + ".heatmaps.1.0", "", true, hidden, NH, 1, 1, 1, ACT_NONE, Builder::ref(X, hidden), Builder::ref(CAT, catc, C)).out_index = out0;
+            b.add(L_GEMM, p + ".pafs.1", p + ".pafs.1.0", "", true, hidden, NP, 1, 1, 1, ACT_NONE, Builder::ref(Y, hidden), Builder::ref(CAT, catc, C + NH)).out_index = out0 + 1;
+            return;
+        }
+        Layer& h0 = b.add(L_GEMM, p + ".heads.0", p + ".heatmaps.0.0", "", true, C, 2 * hidden, 1, 1, 1, ACT_RELU,
+                          Builder::ref(in_buf, C), Builder::ref(H2, 2 * hidden));
+        h0.blocks = {WBlock{p + ".heatmaps.0.0", 0, 0, hidden, C}, WBlock{p + ".pafs.0.0", hidden, 0, hidden, C}};
+        Layer& h1 = b.add(L_GEMM, p + ".heads.1", p + ".heatmaps.1.0", "", true, 2 * hidden, NH + NP, 1, 1, 1, ACT_NONE,
+                          Builder::ref(H2, 2 * hidden), Builder::ref(CAT, catc, C));
+        h1.blocks = {WBlock{p + ".heatmaps.1.0", 0, 0, NH, hidden}, WBlock{p + ".pafs.1.0", NH, hidden, NP, hidden}};
+        h1.out_index = out0; h1.out_index2 = out0 + 1; h1.out_split = NH;
+    };
+    add_heads("initial_stage", S0, 512, 0);
     // refinement stages (with_mobilenet.py:57-60, 82-86)
     for (int k = 0; k < nref; ++k) {
         BufRef in = Builder::ref(CAT, catc, 0);
@@ -189,15 +206,16 @@ Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype) {
             in = Builder::ref(S2, C);
             in_c = C;
         }
-        std::string p = fmt("refinement_stages.%d", k);
-        b.add(L_GEMM, p + ".heatmaps.0", p + ".heatmaps.0.0", "", true, C, C, 1, 1, 1, ACT_RELU, Builder::ref(S2, C), Builder::ref(S0, C));
-        b.add(L_GEMM, p + ".pafs.0", p + ".pafs.0.0", "", true, C, C, 1, 1, 1, ACT_RELU, Builder::ref(S2, C), Builder::ref(S1, C));
-        b.add(L_GEMM, p + ".heatmaps.1", p + ".heatmaps.1.0", "", true, C, NH, 1, 1, 1, ACT_NONE, Builder::ref(S0, C), Builder::ref(CAT, catc, C)).out_index = 2 * (k + 1);
-        b.add(L_GEMM, p + ".pafs.1", p + ".pafs.1.0", "", true, C, NP, 1, 1, 1, ACT_NONE, Builder::ref(S1, C), Builder::ref(CAT, catc, C + NH)).out_index = 2 * (k + 1) + 1;
+        add_heads(fmt("refinement_stages.%d", k), S2, C, 2 * (k + 1));
     }
     // weight blob layout
     size_t off = 0;
     for (Layer& l : g.layers) {
+        if (l.kind == L_STEM) l.macs_per_pixel = 27 * 32;
+        else if (l.kind == L_DW) l.macs_per_pixel = 9 * (int64_t)l.cin;
+        else if (l.kind == L_DWPW) l.macs_per_pixel = 9 * (int64_t)l.cin + (int64_t)l.cin * l.cout;
+        else if (!l.blocks.empty()) { for (const WBlock& wb : l.blocks) l.macs_per_pixel += (int64_t)wb.cin * wb.cout; }
+        else l.macs_per_pixel = (int64_t)l.cin * l.cout * l.ks * l.ks;
         if (l.kind == L_STEM) {
             l.cin_pad = 3; l.cout_pad = 32;
             l.w_off = off; off += 27 * 32;
@@ -270,7 +288,8 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
     for (const Layer& l : g.layers) {
         std::vector<double> scale, shift;
         const int co = (l.kind == L_DWPW) ? l.cin : l.cout;   // channels of the FIRST conv of the layer
-        fold(l.conv_key, l.bn_key, l.has_bias, co, scale, shift);
+        if (l.blocks.empty()) fold(l.conv_key, l.bn_key, l.has_bias, co, scale, shift);
+        else { scale.assign(co, 1.0); shift.assign(co, 0.0); }
         const float* w = f32(l.conv_key + ".weight");
         float* wp = blob.data() + l.w_off;
         float* bp = blob.data() + l.b_off;
@@ -283,6 +302,21 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
         } else if (l.kind == L_DW || l.kind == L_DWPW) {   // (C,1,3,3) -> [tap][C]
             for (int c = 0; c < co; ++c)
                 for (int t = 0; t < 9; ++t) wp[(size_t)t * co + c] = (float)((double)w[c * 9 + t] * scale[c]);
+        } else if (!l.blocks.empty()) {         // merged 1x1 layer: assemble [cout_pad][cin_pad] from its source convs
+            uint16_t* wh = (uint16_t*)wp;
+            for (const WBlock& wb : l.blocks) {
+                const float* ws = f32(wb.conv_key + ".weight");
+                const float* bs = f32(wb.conv_key + ".bias");
+                for (int o = 0; o < wb.cout; ++o) {
+                    bp[wb.out_off + o] = bs[o];
+                    for (int ci = 0; ci < wb.cin; ++ci) {
+                        const size_t idx = (size_t)(wb.out_off + o) * l.cin_pad + wb.in_off + ci;
+                        const float v = ws[(size_t)o * wb.cin + ci];
+                        if (g.dtype == LWP_BF16) wh[idx] = f32_to_bf16_rne(v);
+                        else wp[idx] = v;
+                    }
+                }
+            }
         } else {                                // OIHW -> [tap][cout_pad][cin_pad]  (f32 or bf16)
             const int taps = l.ks * l.ks;
             uint16_t* wh = (uint16_t*)wp;

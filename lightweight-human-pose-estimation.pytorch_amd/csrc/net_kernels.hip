@@ -324,9 +324,11 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(G
                 float v = apply_act(acc[i] + bias, p.act);
                 if (p.res) v += p.res[m * p.res_ld + n];
                 p.out[m * p.out_ld + n] = v;
-                if (p.out_nchw) {
+                if (p.out_nchw || p.out_nchw2) {         // stage outputs (NCHW); merged heads split at out_split
                     const int64_t img = m / HW, pix = m - img * HW;
-                    p.out_nchw[(img * p.cout + n) * HW + pix] = v;
+                    const int c0 = p.out_split > 0 ? p.out_split : p.cout;
+                    if (n < c0) { if (p.out_nchw) p.out_nchw[(img * c0 + n) * HW + pix] = v; }
+                    else if (p.out_nchw2) p.out_nchw2[(img * (p.cout - c0) + (n - c0)) * HW + pix] = v;
                 }
             }
         }

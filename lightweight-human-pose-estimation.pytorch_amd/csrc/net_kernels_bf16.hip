@@ -352,6 +352,11 @@ __global__ void __launch_bounds__((BM / (32 * RM)) * (BN / (32 * RN)) * 64) gemm
         const int64_t m = m0 + (wm * RM + i) * 32 + i32;
         if (m >= M) continue;
         const int64_t img = m / HW, pix = m - img * HW;
+        const int c0 = p.out_split > 0 ? p.out_split : p.cout;
+        auto store_nchw = [&](int ch, float val) {       // stage outputs (NCHW); merged heads split at out_split
+            if (ch < c0) { if (p.out_nchw) p.out_nchw[(img * c0 + ch) * HW + pix] = val; }
+            else if (p.out_nchw2) p.out_nchw2[(img * (p.cout - c0) + (ch - c0)) * HW + pix] = val;
+        };
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
 #pragma unroll
@@ -369,9 +374,9 @@ __global__ void __launch_bounds__((BM / (32 * RM)) * (BN / (32 * RN)) * 64) gemm
                     }
                     bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
                     *(bf16x4*)(out + m * p.out_ld + n) = o;
-                    if (p.out_nchw) {
+                    if (p.out_nchw || p.out_nchw2) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) p.out_nchw[(img * p.cout + n + e) * HW + pix] = v[e];
+                        for (int e = 0; e < 4; ++e) store_nchw(n + e, v[e]);
                     }
                 } else {
 #pragma unroll
@@ -380,7 +385,7 @@ __global__ void __launch_bounds__((BM / (32 * RM)) * (BN / (32 * RN)) * 64) gemm
                             float u = v[e];
                             if (res) u += (float)res[m * p.res_ld + n + e];
                             out[m * p.out_ld + n + e] = (__bf16)u;
-                            if (p.out_nchw) p.out_nchw[(img * p.cout + n + e) * HW + pix] = u;
+                            if (p.out_nchw || p.out_nchw2) store_nchw(n + e, u);
                         }
                     }
                 }

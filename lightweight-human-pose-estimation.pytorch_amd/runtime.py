@@ -212,10 +212,11 @@ class Engine(object):
         out = []
         name = C.create_string_buffer(128)
         v = [C.c_int() for _ in range(6)]
+        macs = C.c_int64()
         for i in range(lib().lwp_layer_count(self.h.ptr)):
-            check(lib().lwp_layer_info(self.h.ptr, i, name, 128, *[C.byref(x) for x in v]), self.h.ptr)
+            check(lib().lwp_layer_info(self.h.ptr, i, name, 128, *[C.byref(x) for x in v], C.byref(macs)), self.h.ptr)
             out.append(dict(index=i, name=name.value.decode(), kind=v[0].value, cin=v[1].value, cout=v[2].value,
-                            ksize=v[3].value, stride=v[4].value, dilation=v[5].value))
+                            ksize=v[3].value, stride=v[4].value, dilation=v[5].value, macs_per_pixel=macs.value))
         return out
 
     def debug_layer_output(self, x, layer_index):

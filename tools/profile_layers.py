@@ -37,10 +37,10 @@ for i, (name, kc, ms) in enumerate(rows):
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         m = a.batch * h * w
         if l["kind"] == 3:
-            fl = 2.0 * m * (9 * l["cin"] + l["cin"] * l["cout"])
+            fl = 2.0 * m * l["macs_per_pixel"]
             rate = "%7.1f TF" % (fl / (ms * 1e-3) / 1e12)
         elif l["kind"] == 2:
-            fl = 2.0 * m * l["cin"] * l["cout"] * l["ksize"] ** 2
+            fl = 2.0 * m * l["macs_per_pixel"]
             rate = "%7.1f TF" % (fl / (ms * 1e-3) / 1e12)
         elif l["kind"] == 1:
             by = (m * l["stride"] ** 2 * l["cin"] + m * l["cout"] + 9 * l["cin"]) * eb
