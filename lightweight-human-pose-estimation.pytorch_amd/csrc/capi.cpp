@@ -176,7 +176,7 @@ extern "C" int lwp_destroy(lwp_handle h) {
         if (sl.ev_maps) (void)hipEventDestroy(sl.ev_maps);
         if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
     }
-    if (h->post_stream) (void)hipStreamDestroy(h->post_stream);
+    if (h->post_stream && h->post_stream != h->stream) (void)hipStreamDestroy(h->post_stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -754,7 +754,11 @@ extern "C" int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, 
     HIP_TRY(h, hipSetDevice(h->device));
     lwp_context::Slot& sl = h->slots[slot];
     if (sl.pending) return fail(h, LWP_ERR_STATE, "slot still pending: call lwp_pipeline_fetch first");
-    if (!h->post_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->post_stream, hipStreamNonBlocking));
+    if (!h->post_stream) {
+        const char* pe = getenv("LWP_POST_STREAM");      // "0": grouping kernels follow the network on the same stream
+        if (pe && pe[0] == '0') h->post_stream = h->stream;
+        else HIP_TRY(h, hipStreamCreateWithFlags(&h->post_stream, hipStreamNonBlocking));
+    }
     if (!sl.ev_maps) {
         HIP_TRY(h, hipEventCreateWithFlags(&sl.ev_maps, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
@@ -787,7 +791,7 @@ extern "C" int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, 
     if (rc) return rc;
     HIP_TRY(h, hipEventRecord(sl.ev_maps, h->stream));
     // post-processing + result copy on the second stream
-    HIP_TRY(h, hipStreamWaitEvent(h->post_stream, sl.ev_maps, 0));
+    if (h->post_stream != h->stream) HIP_TRY(h, hipStreamWaitEvent(h->post_stream, sl.ev_maps, 0));
     const int64_t hw = (int64_t)fh * fw;
     MapView heat{sl.maps[0], (int64_t)g.NH * hw, (int64_t)fw, 1, hw, fh, fw};
     MapView paf{sl.maps[1], (int64_t)g.NP * hw, (int64_t)fw, 1, hw, fh, fw};
