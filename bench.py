@@ -91,8 +91,8 @@ def cpu_baseline(sd, x, nref, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=368)
     ap.add_argument("--width", type=int, default=656)
@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short batch-8/32 fp32 and batch-32 bf16 measurements reported under other_configs")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--preroll", type=float, default=0.3, help="seconds of untimed passes before the warm-up steps (clock ramp)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,6 +153,8 @@ def main():
         eng.infer_poses_async(x, 4, True)
         return eng.fetch_poses()
 
+    _TRACE = [] if os.environ.get("LWP_BENCH_TRACE") else None     # per-iteration host timestamps (diagnostics)
+
     def run_steps(k):
         """k complete passes (results of every pass fetched to the host)."""
         if args.no_pipeline:
@@ -162,6 +165,8 @@ def main():
         pending = []
         r = None
         for i in range(k):
+            if _TRACE is not None:
+                _TRACE.append(time.perf_counter())
             e, slot = engines[i % E], (i // E) & 1
             if len(pending) >= 2 * E:                    # oldest step first: its slot is the one about to be reused
                 pe, ps = pending.pop(0)
@@ -172,12 +177,17 @@ def main():
             r = pe.pipeline_fetch(ps)
         return r
 
-    res = run_steps(max(args.warmup, 1))
-    # a full (generation-2) collection over torch's import graph costs ~40 ms on the submitting thread; take it before
-    # the timed region and park the survivors, as a long-running streaming loop would
+    # a full (generation-2) collection over torch's import graph costs ~40 ms on the submitting thread: take it now and
+    # park the survivors, as a long-running streaming loop would, so it cannot land inside the timed region
     import gc
     gc.collect()
     gc.freeze()
+    # pre-roll (not steps of the measurement): ~0.3 s of the same passes so that the first touch of every slot's
+    # buffers and the GPU's clock ramp from idle are behind us whatever --warmup the caller passes
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.preroll:
+        run_steps(2 * len(engines))
+    res = run_steps(max(args.warmup, 1))
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -192,6 +202,10 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    if _TRACE is not None:
+        d = np.diff(np.array(_TRACE[-args.steps:])) * 1e3
+        print("trace: first 24 iteration gaps (ms):", [round(float(v), 2) for v in d[:24]], "median", round(float(np.median(d)), 3),
+              "slowest", [(int(i), round(float(d[i]), 2)) for i in np.argsort(d)[-5:]], file=sys.stderr)
     if rank == 0:
         total_frames = world * args.batch * args.steps
         # device-only rates (HIP events on the engine's stream) and per-class launch times

@@ -580,7 +580,7 @@ static int parse_results(lwp_context* h, const PostWorkspace& ws, const void* ho
 static int fetch_results(lwp_context* h, int N, int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap, int* n_entries) {
     int rc = ensure_host_stage(h, h->ws.result_bytes + 64);
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpyAsync(h->h_stage, h->ws.result_block, h->ws.result_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, launch_publish(N, h->ws, h->h_stage, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return parse_results(h, h->ws, h->h_stage, N, kpt_counts, kpts, kpt_cap, entries, entry_cap, n_entries);
 }
@@ -800,7 +800,7 @@ extern "C" int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, 
     HIP_TRY(h, launch_score_pairs(paf, N, ratio, demo, sl.ws, h->post_stream));
     HIP_TRY(h, launch_match(N, sl.ws, h->post_stream));
     HIP_TRY(h, launch_assemble(N, sl.ws, h->post_stream));
-    HIP_TRY(h, hipMemcpyAsync(sl.h_stage, sl.ws.result_block, sl.ws.result_bytes, hipMemcpyDeviceToHost, h->post_stream));
+    HIP_TRY(h, launch_publish(N, sl.ws, sl.h_stage, h->post_stream));
     HIP_TRY(h, hipEventRecord(sl.ev_done, h->post_stream));
     sl.pending = true;
     sl.N = N;

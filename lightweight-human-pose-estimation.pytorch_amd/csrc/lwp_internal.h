@@ -174,6 +174,7 @@ hipError_t launch_nms(int N, int ntypes, int Hfull, PostWorkspace& ws, hipStream
 hipError_t launch_score_pairs(const MapView& paf, int N, int ratio, int demo, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_match(int N, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_assemble(int N, PostWorkspace& ws, hipStream_t s);
+hipError_t launch_publish(int N, PostWorkspace& ws, void* host_block, hipStream_t s);   // used rows -> pinned host block
 void build_resize_table(int n_src, int n_dst, std::vector<int>& idx, std::vector<float>& w);
 hipError_t launch_resize_accum(const float* src, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,
                                const int* yi, const float* yw, int dst_h, int dst_w, float divisor, float* accum, hipStream_t s);

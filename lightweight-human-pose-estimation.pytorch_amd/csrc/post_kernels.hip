@@ -185,6 +185,41 @@ hipError_t launch_reset_ws(int N, PostWorkspace& ws, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ result hand-over
+// Writes the USED part of the result block (flags, counts, the first `total` key-point rows and the first
+// n_entries pose rows of every frame) straight into pinned host memory at the same offsets, so the host parses
+// one block.  This replaces a hipMemcpyAsync of the whole block: the runtime may route that through an SDMA
+// queue, which stalls for milliseconds when it has to wake up, and it moves ~115 KB per frame instead of ~10 KB.
+__global__ __launch_bounds__(256) void publish_results_kernel(int N, PostWorkspace ws, char* __restrict__ host) {
+    const int f = blockIdx.y;
+    const PostCaps& c = ws.caps;
+    const size_t WN = (size_t)ws.N;
+    char* q = host;
+    unsigned long long* h_fl = (unsigned long long*)q; q += WN * 4 * 8;
+    double2* h_k = (double2*)q; q += WN * 18 * c.max_kpts * 4 * 8;
+    double2* h_e = (double2*)q; q += WN * c.max_entries * 20 * 8;
+    int* h_cnt = (int*)q; q += WN * 18 * 4;
+    int* h_ne = (int*)q;
+    int total = 0;
+    for (int t = 0; t < 18; ++t) total += ws.kpt_count[f * 18 + t];
+    total = min(max(total, 0), 18 * c.max_kpts);
+    const int ne = min(max(ws.n_entries[f], 0), c.max_entries);
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    if (tid < 4) h_fl[f * 4 + tid] = ws.flags[f * 4 + tid];
+    if (tid >= 32 && tid < 32 + 18) h_cnt[f * 18 + tid - 32] = ws.kpt_count[f * 18 + tid - 32];
+    if (tid == 64) h_ne[f] = ws.n_entries[f];
+    const double2* sk = (const double2*)(ws.kpts_out + (size_t)f * 18 * c.max_kpts * 4);
+    double2* dk = h_k + (size_t)f * 18 * c.max_kpts * 2;
+    for (int i = tid; i < total * 2; i += nth) dk[i] = sk[i];
+    const double2* se = (const double2*)(ws.entries + (size_t)f * c.max_entries * 20);
+    double2* de = h_e + (size_t)f * c.max_entries * 10;
+    for (int i = tid; i < ne * 10; i += nth) de[i] = se[i];
+}
+hipError_t launch_publish(int N, PostWorkspace& ws, void* host_block, hipStream_t s) {
+    hipLaunchKernelGGL(publish_results_kernel, dim3(4, N), dim3(256), 0, s, N, ws, (char*)host_block);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ peaks
 // keypoints.py:17-30: threshold, zero border, strict > against the 4 neighbours.
 // One PTH x PTW tile of full-res pixels per workgroup.  For R = 4 / 8 the up-sampled values (tile + halo 1) are
