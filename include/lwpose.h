@@ -91,6 +91,18 @@ int lwp_weights_blob_import(lwp_handle h, const void* src_device, size_t bytes);
 int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int H, int W,
                 float* const* outs, int out_mem);
 
+/* ---- frame pre-processing on the device: replaces demo.py:55-64 (scale = net_input_height / H; cv2.resize of the
+ *      uint8 frame with fx = fy = scale, INTER_CUBIC; normalize, val.py:30-33; pad_width, val.py:36-49; HWC -> 1x3xHxW
+ *      float32).  lwp_preprocess_dims is pure host arithmetic: the scaled size (round half to even of H*scale, W*scale),
+ *      the padded size out_h x out_w, pad = [top, left, bottom, right] and scale, exactly as infer_fast returns them.
+ *      lwp_preprocess_u8: img is H x W x 3 uint8 (mem), out is a DEVICE buffer of 3*out_h*out_w float32.
+ *      pad_value / img_mean: 3 doubles each (the reference's defaults are (0,0,0) and (128,128,128)); img_scale 1/256.
+ *      The pad value is written as is (the reference pads AFTER normalising).  Runs on the handle's stream. */
+int lwp_preprocess_dims(int H, int W, int net_input_height, int stride, int* scaled_h, int* scaled_w,
+                        int* out_h, int* out_w, int* pad, double* scale);
+int lwp_preprocess_u8(lwp_handle h, const unsigned char* img, int img_mem, int H, int W, int net_input_height, int stride,
+                      const double* pad_value, const double* img_mean, double img_scale, float* out_device);
+
 /* ---- bicubic up-sampling: replaces cv2.resize(map, (0,0), fx=r, fy=r, INTER_CUBIC) on float maps
  *      (demo.py:72,76; val.py:98,105).  src: N x C x h x w (mem);  dst: N x (h*r) x (w*r) x C (mem). */
 int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, int C, int hs, int ws, int ratio,

@@ -1,6 +1,7 @@
 // C-ABI entry points (include/lwpose.h).  Host orchestration only: buffer management, the static
 // launch sequence of the layer graph on the handle's HIP stream, result fetch, and event timing.
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +30,9 @@ struct lwp_context {
     float* d_tmp = nullptr; size_t d_tmp_bytes = 0;     // generic device staging (upsample / extract / group)
     float* d_tmp2 = nullptr; size_t d_tmp2_bytes = 0;
     float* d_tab = nullptr; size_t d_tab_bytes = 0;     // resize tables
+    float* d_img = nullptr; size_t d_img_bytes = 0;     // uint8 frame staging (pre-processing of host frames)
+    float* d_pre_tab = nullptr; size_t d_pre_tab_bytes = 0;   // fixed-point resize tables, cached for (pre_H, pre_W, pre_net_h)
+    int pre_H = 0, pre_W = 0, pre_net_h = 0;
     float* d_maps[2] = {nullptr, nullptr}; size_t d_maps_bytes[2] = {0, 0};   // bf16 path: f32 NCHW heat / PAF of the last stage
     // post-processing
     PostCaps caps;
@@ -164,6 +168,8 @@ extern "C" int lwp_destroy(lwp_handle h) {
     if (h->d_tmp2) (void)hipFree(h->d_tmp2);
     for (float* p : h->d_maps) if (p) (void)hipFree(p);
     if (h->d_tab) (void)hipFree(h->d_tab);
+    if (h->d_img) (void)hipFree(h->d_img);
+    if (h->d_pre_tab) (void)hipFree(h->d_pre_tab);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_zeros) (void)hipFree(h->d_zeros);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -528,6 +534,75 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, d_acc, h->stream));
     if (accum_mem == LWP_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(accum, d_acc, ab, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));      // the host tables go out of scope
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- pre-processing
+extern "C" int lwp_preprocess_dims(int H, int W, int net_input_height, int stride, int* scaled_h, int* scaled_w,
+                                   int* out_h, int* out_w, int* pad, double* scale) {
+    if (H <= 0 || W <= 0 || net_input_height <= 0 || stride <= 0 || !scaled_h || !scaled_w || !out_h || !out_w || !pad || !scale)
+        return fail(nullptr, LWP_ERR_ARG, "bad argument");
+    const double sc = (double)net_input_height / (double)H;                       // demo.py:57
+    const int dw = (int)nearbyint((double)W * sc), dh = (int)nearbyint((double)H * sc);   // cv2 dsize: round half to even
+    if (dw <= 0 || dh <= 0) return fail(nullptr, LWP_ERR_ARG, "scaled frame is empty");
+    // val.py:36-49 with min_dims = [net_input_height, max(dw, net_input_height)] (demo.py:61)
+    const int h = dh < net_input_height ? dh : net_input_height;
+    const int min0 = (int)ceil(net_input_height / (double)stride) * stride;
+    const int m1 = dw > net_input_height ? dw : net_input_height;
+    const int min1 = (int)ceil(m1 / (double)stride) * stride;
+    pad[0] = (int)floor((min0 - h) / 2.0);
+    pad[1] = (int)floor((min1 - dw) / 2.0);
+    pad[2] = min0 - h - pad[0];
+    pad[3] = min1 - dw - pad[1];
+    *scaled_h = dh; *scaled_w = dw;
+    *out_h = dh + pad[0] + pad[2];
+    *out_w = dw + pad[1] + pad[3];
+    *scale = sc;
+    return LWP_OK;
+}
+
+extern "C" int lwp_preprocess_u8(lwp_handle h, const unsigned char* img, int img_mem, int H, int W, int net_input_height,
+                                 int stride, const double* pad_value, const double* img_mean, double img_scale, float* out_device) {
+    if (!h || !img || !pad_value || !img_mean || !out_device) return fail(h, LWP_ERR_ARG, "null argument");
+    int dh, dw, Hp, Wp, pad[4];
+    double sc;
+    int rc = lwp_preprocess_dims(H, W, net_input_height, stride, &dh, &dw, &Hp, &Wp, pad, &sc);
+    if (rc) return fail(h, rc, "bad frame / network size");
+    if (pad[0] < 0 || pad[1] < 0 || pad[2] < 0 || pad[3] < 0) return fail(h, LWP_ERR_ARG, "negative padding");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const unsigned char* d_src = img;
+    if (img_mem == LWP_MEM_HOST) {
+        const size_t ib = (size_t)H * W * 3;
+        rc = ensure_dev(h, &h->d_img, &h->d_img_bytes, ib);
+        if (rc) return rc;
+        HIP_TRY(h, hipMemcpyAsync(h->d_img, img, ib, hipMemcpyHostToDevice, h->stream));
+        d_src = (const unsigned char*)h->d_img;
+    }
+    const size_t nx = (size_t)dw * 4, ny = (size_t)dh * 4;
+    if (h->pre_H != H || h->pre_W != W || h->pre_net_h != net_input_height) {   // tables depend on the geometry only
+        std::vector<int> xi, xw, yi, yw;
+        build_resize_table_u8(W, dw, sc, xi, xw);
+        build_resize_table_u8(H, dh, sc, yi, yw);
+        HIP_TRY(h, hipStreamSynchronize(h->stream));                            // an earlier launch may still read the old tables
+        rc = ensure_dev(h, &h->d_pre_tab, &h->d_pre_tab_bytes, (nx + ny) * 8);
+        if (rc) return rc;
+        int* t = (int*)h->d_pre_tab;
+        HIP_TRY(h, hipMemcpy(t, xi.data(), nx * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(t + nx, xw.data(), nx * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(t + 2 * nx, yi.data(), ny * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(t + 2 * nx + ny, yw.data(), ny * 4, hipMemcpyHostToDevice));
+        h->pre_H = H; h->pre_W = W; h->pre_net_h = net_input_height;
+    }
+    const int* t = (const int*)h->d_pre_tab;
+    PreprocParams p;
+    p.src = d_src; p.Hs = H; p.Ws = W;
+    p.xi = t; p.xw = t + nx; p.yi = t + 2 * nx; p.yw = t + 2 * nx + ny;
+    p.dh = dh; p.dw = dw; p.top = pad[0]; p.left = pad[1]; p.Hp = Hp; p.Wp = Wp;
+    for (int c = 0; c < 3; ++c) { p.mean[c] = img_mean[c]; p.pad_value[c] = (float)pad_value[c]; }
+    p.scale = img_scale;
+    p.out = out_device;
+    LAUNCH(h, KC_POST, launch_preprocess_u8(p, h->stream));
+    if (img_mem == LWP_MEM_HOST) HIP_TRY(h, hipStreamSynchronize(h->stream));   // the caller may reuse its frame buffer
     return LWP_OK;
 }
 

@@ -174,6 +174,17 @@ hipError_t launch_nms(int N, int ntypes, int Hfull, PostWorkspace& ws, hipStream
 hipError_t launch_score_pairs(const MapView& paf, int N, int ratio, int demo, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_match(int N, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_assemble(int N, PostWorkspace& ws, hipStream_t s);
+// u8 frame -> resized, normalised, padded CHW float32 (demo.py:59-64)
+struct PreprocParams {
+    const unsigned char* src; int Hs, Ws;            // HWC uint8, 3 channels
+    const int *xi, *xw, *yi, *yw;                    // per destination index: 4 clamped source indices, 4 fixed-point weights
+    int dh, dw, top, left, Hp, Wp;                   // scaled size, its offset inside the padded Hp x Wp frame
+    double mean[3], scale;
+    float pad_value[3];
+    float* out;                                      // 3 x Hp x Wp
+};
+void build_resize_table_u8(int n_src, int n_dst, double inv_scale, std::vector<int>& idx, std::vector<int>& w);
+hipError_t launch_preprocess_u8(const PreprocParams& p, hipStream_t s);
 hipError_t launch_publish(int N, PostWorkspace& ws, void* host_block, hipStream_t s);   // used rows -> pinned host block
 void build_resize_table(int n_src, int n_dst, std::vector<int>& idx, std::vector<float>& w);
 hipError_t launch_resize_accum(const float* src, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,

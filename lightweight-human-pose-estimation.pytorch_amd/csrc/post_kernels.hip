@@ -185,6 +185,71 @@ hipError_t launch_reset_ws(int N, PostWorkspace& ws, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ u8 pre-processing
+// demo.py:59-64 on the device: cv2.resize(img, fx=fy=scale, INTER_CUBIC) of the uint8 HWC frame with OpenCV's
+// fixed-point path (4 taps per axis, float32 cubic coefficients (A = -0.75) scaled by 2048 and rounded to short,
+// horizontal then vertical integer sums, (v + 2^21) >> 22, saturate), then normalize (val.py:30-33: float64
+// (u8 - mean) * scale) and pad_width (val.py:36-49: constant border) and HWC -> CHW float32 — one kernel, one
+// thread per output pixel.  Integer arithmetic, so the summation order is immaterial.
+void build_resize_table_u8(int n_src, int n_dst, double inv_scale, std::vector<int>& idx, std::vector<int>& w) {
+    const double scale = 1.0 / inv_scale;
+    idx.resize((size_t)n_dst * 4);
+    w.resize((size_t)n_dst * 4);
+    for (int d = 0; d < n_dst; ++d) {
+        const float fx = (float)(((double)d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(fx);
+        volatile float frac = fx - (float)s;
+        float c[4];
+        cubic_coeffs_host(frac, c);
+        for (int k = 0; k < 4; ++k) {
+            int j = s - 1 + k;
+            idx[(size_t)d * 4 + k] = j < 0 ? 0 : (j > n_src - 1 ? n_src - 1 : j);
+            volatile float scaled = c[k] * 2048.f;
+            double r = nearbyint((double)scaled);                    // round half to even, like np.rint / cvRound
+            r = r < -32768.0 ? -32768.0 : (r > 32767.0 ? 32767.0 : r);
+            w[(size_t)d * 4 + k] = (int)r;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) preprocess_u8_kernel(PreprocParams p) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= p.Wp) return;
+    const int yy = y - p.top, xx = x - p.left;
+    const int64_t plane = (int64_t)p.Hp * p.Wp;
+    float* o = p.out + (int64_t)y * p.Wp + x;
+    if (yy < 0 || yy >= p.dh || xx < 0 || xx >= p.dw) {
+        o[0] = p.pad_value[0]; o[plane] = p.pad_value[1]; o[2 * plane] = p.pad_value[2];
+        return;
+    }
+    int xo[4], wx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { xo[k] = p.xi[xx * 4 + k] * 3; wx[k] = p.xw[xx * 4 + k]; }
+    long long acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const unsigned char* row = p.src + (int64_t)p.yi[yy * 4 + ky] * p.Ws * 3;
+        const long long wy = p.yw[yy * 4 + ky];
+        int t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const unsigned char* q = row + xo[kx];
+            t0 += (int)q[0] * wx[kx]; t1 += (int)q[1] * wx[kx]; t2 += (int)q[2] * wx[kx];
+        }
+        acc[0] += t0 * wy; acc[1] += t1 * wy; acc[2] += t2 * wy;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        long long v = (acc[c] + (1ll << 21)) >> 22;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        o[c * plane] = (float)__dmul_rn(__dsub_rn((double)v, p.mean[c]), p.scale);
+    }
+}
+hipError_t launch_preprocess_u8(const PreprocParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3((p.Wp + 255) / 256, p.Hp), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ result hand-over
 // Writes the USED part of the result block (flags, counts, the first `total` key-point rows and the first
 // n_entries pose rows of every frame) straight into pinned host memory at the same offsets, so the host parses

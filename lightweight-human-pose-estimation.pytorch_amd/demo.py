@@ -9,23 +9,16 @@ import numpy as np
 
 from .modules.keypoints import extract_keypoints, group_keypoints
 from .modules.pose import Pose, track_poses
-from .val import normalize, pad_width, resize_cubic_u8
 
 
-def _prepare(img, net_input_height_size, stride, pad_value, img_mean, img_scale):
-    height, width, _ = img.shape
-    scale = net_input_height_size / height
-    scaled_img = resize_cubic_u8(img, scale, scale)
-    scaled_img = normalize(scaled_img, img_mean, img_scale)
-    min_dims = [net_input_height_size, max(scaled_img.shape[1], net_input_height_size)]
-    padded_img, pad = pad_width(scaled_img, stride, pad_value, min_dims)
-    x = np.ascontiguousarray(padded_img.transpose(2, 0, 1)[None], dtype=np.float32)
-    return x, scale, pad
+def _prepare(net, img, net_input_height_size, stride, pad_value, img_mean, img_scale):
+    """demo.py:55-64 (resize by height, normalize, pad, to tensor) as one GPU kernel: uint8 frame -> cuda tensor."""
+    return net.engine.preprocess_u8(img, net_input_height_size, stride, pad_value, img_mean, img_scale)
 
 
 def infer_fast(net, img, net_input_height_size, stride, upsample_ratio, cpu,
                pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
-    x, scale, pad = _prepare(img, net_input_height_size, stride, pad_value, img_mean, img_scale)
+    x, scale, pad = _prepare(net, img, net_input_height_size, stride, pad_value, img_mean, img_scale)
     stages_output = net(x)                       # numpy in -> numpy out; `cpu` is accepted and ignored
     eng = net.engine
     heatmaps = eng.upsample(stages_output[-2], upsample_ratio)[0]
@@ -60,7 +53,7 @@ def run_demo(net, image_provider, height_size, cpu, track, smooth, fused=False, 
     previous_poses = []
     for img in image_provider:
         if fused:
-            x, scale, pad = _prepare(img, height_size, stride, (0, 0, 0), (128, 128, 128), 1 / 256)
+            x, scale, pad = _prepare(net, img, height_size, stride, (0, 0, 0), (128, 128, 128), 1 / 256)
             pose_entries, all_keypoints, _ = net.engine.infer_poses(x, upsample_ratio, demo=True)[0]
         else:
             heatmaps, pafs, scale, pad = infer_fast(net, img, height_size, stride, upsample_ratio, cpu)

@@ -111,6 +111,40 @@ class Engine(object):
         check(lib().lwp_upsample(self.h.ptr, ptr, mem, N, Cc, h, w, ratio, out.ctypes.data, MEM_HOST), self.h.ptr)
         return out
 
+    @staticmethod
+    def preprocess_dims(height, width, net_input_height_size, stride):
+        """(scaled_h, scaled_w, out_h, out_w, pad [top,left,bottom,right], scale) of demo.py:55-62 for a height x width frame."""
+        v = [C.c_int() for _ in range(4)]
+        pad = (C.c_int * 4)()
+        sc = C.c_double()
+        check(lib().lwp_preprocess_dims(height, width, net_input_height_size, stride, *[C.byref(a) for a in v], pad, C.byref(sc)))
+        return v[0].value, v[1].value, v[2].value, v[3].value, [int(a) for a in pad], sc.value
+
+    def preprocess_u8(self, img, net_input_height_size, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1 / 256):
+        """uint8 HxWx3 frame (numpy or cuda tensor) -> (x: 1x3xH'xW' float32 cuda tensor, scale, pad): the cubic resize,
+        normalize and pad_width of demo.py:55-64 in one kernel."""
+        torch = _torch()
+        if getattr(img, "is_cuda", False):
+            if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+                raise TypeError("frame must be HxWx3 uint8")
+            a = img.contiguous()
+            torch.cuda.current_stream(a.device).synchronize()
+            ptr, mem = a.data_ptr(), MEM_DEVICE
+        else:
+            a = np.ascontiguousarray(img)
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+                raise TypeError("frame must be HxWx3 uint8")
+            ptr, mem = a.ctypes.data, MEM_HOST
+        H, W = int(a.shape[0]), int(a.shape[1])
+        _, _, oh, ow, pad, scale = self.preprocess_dims(H, W, net_input_height_size, stride)
+        x = torch.empty((1, 3, oh, ow), dtype=torch.float32, device=torch.device("cuda", self.device_id))
+        pv = (C.c_double * 3)(*[float(v) for v in pad_value])
+        mv = (C.c_double * 3)(*[float(v) for v in img_mean])
+        check(lib().lwp_preprocess_u8(self.h.ptr, ptr, mem, H, W, net_input_height_size, stride, pv, mv, float(img_scale), x.data_ptr()), self.h.ptr)
+        if mem == MEM_DEVICE:
+            self.synchronize()
+        return x, scale, pad
+
     def multiscale_accumulate(self, accum, maps, up_ratio, pad, n_scales):
         """accum (H,W,C) float32 [numpy or cuda tensor, updated in place] += resize(crop(upsample(maps))) / n_scales
         (val.py:96-101).  maps: (1,C,h,w) or (C,h,w) float32 numpy / cuda tensor."""

@@ -1,8 +1,8 @@
 """Host pre-processing helpers with the reference's names and semantics (reference: val.py:30-49).
 
-OpenCV is not a dependency: ``cv2.copyMakeBorder(BORDER_CONSTANT)`` is a constant fill + copy and the
-uint8 ``cv2.resize(INTER_CUBIC)`` is restated from OpenCV's fixed-point algorithm (11-bit coefficients,
-A = -0.75) — unpinned against cv2 itself, which is absent from the build container.
+OpenCV is not a dependency: ``cv2.copyMakeBorder(BORDER_CONSTANT)`` is a constant fill + copy.  The uint8
+``cv2.resize(INTER_CUBIC)`` of demo.py:59 runs on the GPU (``Engine.preprocess_u8``, OpenCV's fixed-point
+algorithm: 11-bit coefficients, A = -0.75) — unpinned against cv2 itself, which is absent from the build container.
 """
 import math
 
@@ -37,33 +37,6 @@ def _cubic_coeffs_f32(x):
     c1 = ((A + f(2)) * x - (A + f(3))) * x * x + f(1)
     c2 = ((A + f(2)) * (f(1) - x) - (A + f(3))) * (f(1) - x) * (f(1) - x) + f(1)
     return np.array([c0, c1, c2, f(1) - c0 - c1 - c2], dtype=np.float32)
-
-
-def _axis_tables_u8(n_src, n_dst, inv_scale):
-    d = np.arange(n_dst)
-    f = ((d + 0.5) * (1.0 / inv_scale) - 0.5).astype(np.float32)
-    s = np.floor(f).astype(np.int64)
-    frac = f - s.astype(np.float32)
-    idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
-    w = np.stack([_cubic_coeffs_f32(t) for t in frac]) * np.float32(2048)
-    return idx, np.clip(np.rint(w), -32768, 32767).astype(np.int64)
-
-
-def resize_cubic_u8(img, fx, fy):
-    """cv2.resize(img, (0,0), fx=fx, fy=fy, interpolation=cv2.INTER_CUBIC) for uint8 HxWxC images (demo.py:59)."""
-    img = np.asarray(img)
-    if img.dtype != np.uint8:
-        raise TypeError("resize_cubic_u8 expects uint8")
-    h, w = img.shape[:2]
-    dw, dh = int(round(w * fx)), int(round(h * fy))
-    if (dw, dh) == (w, h) and fx == 1 and fy == 1:
-        return img.copy()
-    xi, xw = _axis_tables_u8(w, dw, fx)
-    yi, yw = _axis_tables_u8(h, dh, fy)
-    src = img.astype(np.int64)
-    t = sum(src[:, xi[:, k]] * xw[None, :, k, None] for k in range(4))
-    o = sum(t[yi[:, k]] * yw[:, k, None, None] for k in range(4))
-    return np.clip((o + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
 
 
 def resize_cubic_float(img, ratio):

@@ -481,3 +481,44 @@ def test_val_infer_multiscale_matches_oracle():
     ref_h, ref_p = preproc_ref.infer(sd, 3, img, [0.5, 1.0, 1.5], 184, 8)
     assert got_h.shape == (92, 120, 19) and got_p.shape == (92, 120, 38)
     assert np.abs(got_h - ref_h).max() <= 2e-3 and np.abs(got_p - ref_p).max() <= 2e-3
+
+
+# ------------------------------------------------------------------------------------------ u8 pre-processing (demo.py:55-64)
+@pytest.mark.parametrize("H,W,net_h,stride", [(368, 656, 368, 8), (480, 640, 368, 8), (200, 300, 368, 8), (721, 1283, 368, 8),
+                                               (1080, 1920, 256, 8), (333, 111, 368, 8), (64, 96, 64, 16)])
+def test_preprocess_u8_is_bit_exact(eng, H, W, net_h, stride):
+    """Fixed-point cubic resize + normalize + pad + HWC->CHW in one kernel vs the oracle (integer + exact f64 -> f32)."""
+    from oracle import preproc_ref
+    img = synth.make_frames(1, H, W, seed0=H + W)[0]
+    want, scale, pad = preproc_ref.prepare_frame(img, net_h, stride)
+    x, scale2, pad2 = eng.preprocess_u8(img, net_h, stride)
+    assert scale2 == scale and pad2 == pad and tuple(x.shape) == want.shape and x.dtype == torch.float32
+    assert np.array_equal(x.cpu().numpy(), want)
+    xd, _, _ = eng.preprocess_u8(torch.from_numpy(img).cuda(), net_h, stride)      # frame already in HBM
+    assert np.array_equal(xd.cpu().numpy(), want)
+
+
+def test_preprocess_u8_non_default_mean_scale_pad(eng):
+    from oracle import preproc_ref
+    img = synth.make_frames(1, 240, 200, seed0=9)[0]
+    kw = dict(pad_value=(3, 7.5, -2), img_mean=(104.5, 117, 123), img_scale=1 / 57.375)
+    want, scale, pad = preproc_ref.prepare_frame(img, 368, 8, **kw)
+    x, scale2, pad2 = eng.preprocess_u8(img, 368, 8, **kw)
+    assert scale2 == scale and pad2 == pad and np.array_equal(x.cpu().numpy(), want)
+    assert pad[1] > 0 and want[0, 1, 0, 0] == np.float32(7.5)
+
+
+def test_infer_fast_from_u8_frame_matches_oracle_pipeline():
+    """demo.infer_fast end to end from a uint8 frame that needs resizing: maps within the network tolerance of the
+    oracle (oracle pre-processing -> oracle forward -> oracle x4 cubic up-sampling), same scale and pad."""
+    from lwpose_amd.demo import infer_fast
+    from oracle import preproc_ref
+    net, sd = get_net(1, 5)
+    img = synth.make_frames(1, 300, 500, seed0=21)[0]
+    heat, paf, scale, pad = infer_fast(net, img, 368, 8, 4, False)
+    x, s2, p2 = preproc_ref.prepare_frame(img, 368, 8)
+    outs = net_ref.forward(sd, torch.from_numpy(x), 1)
+    wh = post_ref.upsample_cubic(outs[-2][0].numpy().transpose(1, 2, 0), 4)
+    wp = post_ref.upsample_cubic(outs[-1][0].numpy().transpose(1, 2, 0), 4)
+    assert scale == s2 and pad == p2 and heat.shape == wh.shape and paf.shape == wp.shape
+    assert np.abs(heat - wh).max() <= NET_TOL and np.abs(paf - wp).max() <= NET_TOL

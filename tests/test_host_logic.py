@@ -13,7 +13,8 @@ import torch
 
 import lwpose_amd  # noqa: F401
 from lwpose_amd import _lib, arch, dist as lwdist, synth
-from lwpose_amd.val import normalize, pad_width, resize_cubic_u8
+from lwpose_amd.val import normalize, pad_width
+from oracle import preproc_ref
 
 from conftest import GOLDEN, ROOT
 
@@ -79,13 +80,37 @@ def test_pad_width_semantics():
     assert pad == [92, 20, 92, 20] and out.shape == (368, 368, 3)
 
 
-def test_resize_cubic_u8_identity_and_range():
+def test_oracle_resize_cubic_u8_identity_range_and_float_cross_check():
+    """The oracle's restatement of OpenCV's fixed-point uint8 cubic resize (demo.py:59; cv2 absent -> unpinned vs cv2):
+    identity at scale 1, constants stay constant, and it stays within 1 grey level of the rounded float bicubic
+    (torch, A = -0.75, same half-pixel mapping and border clamp)."""
     img = synth.make_frames(1, 40, 56)[0]
-    assert np.array_equal(resize_cubic_u8(img, 1.0, 1.0), img)
-    up = resize_cubic_u8(img, 2.0, 2.0)
-    assert up.shape == (80, 112, 3) and up.dtype == np.uint8
+    assert np.array_equal(preproc_ref.resize_cubic_u8(img, 1.0, 1.0), img)
     const = np.full((20, 30, 3), 77, np.uint8)
-    assert np.array_equal(resize_cubic_u8(const, 1.7, 1.7), np.full((34, 51, 3), 77, np.uint8))
+    assert np.array_equal(preproc_ref.resize_cubic_u8(const, 1.7, 1.7), np.full((34, 51, 3), 77, np.uint8))
+    smooth = torch.nn.functional.interpolate(torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None], scale_factor=4,
+                                             mode="bilinear").clamp(0, 255).round()[0].permute(1, 2, 0).numpy().astype(np.uint8)
+    for fx in (2.0, 1.5, 0.75):
+        up = preproc_ref.resize_cubic_u8(smooth, fx, fx)
+        t = torch.from_numpy(smooth.astype(np.float32)).permute(2, 0, 1)[None]
+        ref = torch.nn.functional.interpolate(t, size=up.shape[:2], scale_factor=None, mode="bicubic", align_corners=False)
+        if fx == 2.0:                                # torch derives the same scale from the sizes only when they divide exactly
+            ref = ref.clamp(0, 255)[0].permute(1, 2, 0).numpy()
+            assert up.shape == (320, 448, 3) and up.dtype == np.uint8
+            assert np.abs(up.astype(np.float32) - ref).max() <= 1.0 + 1e-3
+        assert up.dtype == np.uint8 and up.shape[2] == 3
+
+
+@pytest.mark.parametrize("H,W,net_h,stride", [(368, 656, 368, 8), (480, 640, 368, 8), (200, 300, 368, 8), (721, 1283, 368, 8),
+                                               (1080, 1920, 256, 8), (333, 111, 368, 8), (64, 96, 64, 16)])
+def test_preprocess_dims_match_the_oracle(H, W, net_h, stride):
+    """lwp_preprocess_dims (pure host arithmetic of the C-ABI library) against the oracle's demo.py:55-62 restatement."""
+    from lwpose_amd.runtime import Engine
+    img = np.zeros((H, W, 3), np.uint8)
+    x, scale, pad = preproc_ref.prepare_frame(img, net_h, stride)
+    dh, dw, oh, ow, pad2, scale2 = Engine.preprocess_dims(H, W, net_h, stride)
+    assert (oh, ow) == x.shape[2:] and pad2 == pad and scale2 == scale
+    assert (dh, dw) == (int(round(H * scale)), int(round(W * scale)))
 
 
 def test_one_euro_filter_matches_reference_sequence():

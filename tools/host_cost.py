@@ -33,3 +33,13 @@ c = []
 for i in range(20):
     t = time.perf_counter(); engs[0].pipeline_submit(x, 0); c.append(time.perf_counter() - t); engs[0].pipeline_fetch(0)
 print("idle submit us", np.median(c) * 1e6)
+# pure host cost of a fetch whose results are already complete
+c = []
+for i in range(50):
+    engs[0].pipeline_submit(x, 0); torch.cuda.synchronize(); time.sleep(0.002)
+    t = time.perf_counter(); engs[0].pipeline_fetch(0); c.append(time.perf_counter() - t)
+print("completed-fetch us", np.median(c) * 1e6)
+import cProfile, pstats
+engs[0].pipeline_submit(x, 0); torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable(); engs[0].pipeline_fetch(0); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(12)
