@@ -41,6 +41,7 @@ enum {
 };
 
 enum { LWP_MEM_HOST = 0, LWP_MEM_DEVICE = 1 };
+enum { LWP_LAYOUT_NCHW = 0, LWP_LAYOUT_NHWC = 1 };
 enum { LWP_F32 = 0, LWP_BF16 = 1 };   /* storage/MFMA dtype of the conv stack; accumulation, bias,
                                          activations and all post-processing are always f32/f64 */
 
@@ -110,8 +111,9 @@ int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, int C, int 
 
 /* ---- one scale of the multi-scale average: replaces val.py:96-101 / 103-108 (x`up_ratio` cubic up-sampling of one
  *      stage output, crop of the padding pad = [top, left, bottom, right], cubic resize to (dst_w, dst_h),
- *      accum = accum + maps / n_scales).  maps: 1 x C x hs x ws float32 (mem); accum: dst_h x dst_w x C float32 HWC (mem). */
-int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int maps_mem, int C, int hs, int ws, int up_ratio,
+ *      accum = accum + maps / n_scales).  maps: N x C x hs x ws float32 (mem); accum: N x dst_h x dst_w x C float32 HWC (mem);
+ *      the N frames share one geometry (same pad, same destination size). */
+int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int maps_mem, int N, int C, int hs, int ws, int up_ratio,
                               const int* pad, int dst_h, int dst_w, int n_scales, float* accum, int accum_mem);
 
 /* ---- extract_keypoints: replaces modules/keypoints.py:16-48 for one heat-map channel.
@@ -142,9 +144,10 @@ int lwp_infer_poses(lwp_handle h, const float* in, int in_mem, int N, int H, int
                     int* kpt_counts, double* kpts, int kpt_cap,
                     double* entries, int entry_cap, int* n_entries);
 
-/* same post-processing from already computed low-resolution stage outputs (the tensors net(x) returns,
- * demo.py:70,74): heat N x num_heatmaps x h x w, paf N x num_pafs x h x w, NCHW float32 (mem). */
-int lwp_poses_from_maps(lwp_handle h, const float* heat, const float* paf, int mem, int N, int hs, int ws,
+/* same post-processing from already computed maps: the low-resolution stage outputs net(x) returns (demo.py:70,74),
+ * heat N x num_heatmaps x h x w, paf N x num_pafs x h x w, LWP_LAYOUT_NCHW; or the full-resolution averaged maps of the
+ * multi-scale path (val.py:129-134), N x h x w x C, LWP_LAYOUT_NHWC with upsample_ratio = 1.  float32 (mem). */
+int lwp_poses_from_maps(lwp_handle h, const float* heat, const float* paf, int mem, int layout, int N, int hs, int ws,
                         int upsample_ratio, int demo,
                         int* kpt_counts, double* kpts, int kpt_cap,
                         double* entries, int entry_cap, int* n_entries);

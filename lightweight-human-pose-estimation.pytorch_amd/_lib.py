@@ -60,12 +60,12 @@ def lib():
     L.lwp_time_pipeline.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
     L.lwp_profile_classes.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, ip]
     L.lwp_synchronize.argtypes = [vp]
-    L.lwp_poses_from_maps.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, vp, C.c_int, vp, C.c_int, ip]
+    L.lwp_poses_from_maps.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, vp, C.c_int, vp, C.c_int, ip]
     L.lwp_profile_launches.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, ip, C.c_int, ip]
     L.lwp_debug_time_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
     L.lwp_pipeline_submit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lwp_pipeline_fetch.argtypes = [vp, C.c_int, ip, vp, C.c_int, vp, C.c_int, ip]
-    L.lwp_multiscale_accumulate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.lwp_multiscale_accumulate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, vp, C.c_int]
     dp = C.POINTER(C.c_double)
     L.lwp_preprocess_dims.argtypes = [C.c_int] * 4 + [ip] * 5 + [dp]
     L.lwp_preprocess_u8.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, vp]

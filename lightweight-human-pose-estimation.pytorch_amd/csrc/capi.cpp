@@ -486,16 +486,16 @@ extern "C" int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, 
 }
 
 // ---------------------------------------------------------------------------------------------- multi-scale accumulate
-extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int maps_mem, int C, int hs, int ws, int up_ratio,
+extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int maps_mem, int N, int C, int hs, int ws, int up_ratio,
                                          const int* pad, int dst_h, int dst_w, int n_scales, float* accum, int accum_mem) {
-    if (!h || !maps || !pad || !accum || C <= 0 || hs <= 0 || ws <= 0 || dst_h <= 0 || dst_w <= 0 || n_scales <= 0)
+    if (!h || !maps || !pad || !accum || N <= 0 || C <= 0 || hs <= 0 || ws <= 0 || dst_h <= 0 || dst_w <= 0 || n_scales <= 0)
         return fail(h, LWP_ERR_ARG, "bad argument");
     if (up_ratio != 4 && up_ratio != 8) return fail(h, LWP_ERR_ARG, "upsample ratio must be 4 or 8");
     const int Hs = hs * up_ratio, Ws = ws * up_ratio;
     const int ch = Hs - pad[0] - pad[2], cw = Ws - pad[1] - pad[3];
     if (pad[0] < 0 || pad[1] < 0 || pad[2] < 0 || pad[3] < 0 || ch <= 0 || cw <= 0) return fail(h, LWP_ERR_ARG, "bad crop");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t sb = (size_t)C * hs * ws * sizeof(float), ub = sb * up_ratio * up_ratio, ab = (size_t)dst_h * dst_w * C * sizeof(float);
+    const size_t sb = (size_t)N * C * hs * ws * sizeof(float), ub = sb * up_ratio * up_ratio, ab = (size_t)N * dst_h * dst_w * C * sizeof(float);
     const float* d_src = maps;
     int rc;
     if (maps_mem == LWP_MEM_HOST) {
@@ -530,8 +530,8 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     HIP_TRY(h, hipMemcpyAsync(d_yi, yi.data(), yi.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(d_yw, yw.data(), yw.size() * 4, hipMemcpyHostToDevice, h->stream));
     MapView v{d_src, (int64_t)C * hs * ws, (int64_t)ws, 1, (int64_t)hs * ws, hs, ws};
-    LAUNCH(h, KC_POST, launch_upsample(v, 1, C, up_ratio, h->d_tmp2, h->stream));
-    LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, d_acc, h->stream));
+    LAUNCH(h, KC_POST, launch_upsample(v, N, C, up_ratio, h->d_tmp2, h->stream));
+    LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, N, Hs, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, d_acc, h->stream));
     if (accum_mem == LWP_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(accum, d_acc, ab, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));      // the host tables go out of scope
     return LWP_OK;
@@ -893,12 +893,13 @@ extern "C" int lwp_pipeline_fetch(lwp_handle h, int slot, int* kpt_counts, doubl
     return parse_results(h, sl.ws, sl.h_stage, sl.N, kpt_counts, kpts, kpt_cap, entries, entry_cap, n_entries);
 }
 
-extern "C" int lwp_poses_from_maps(lwp_handle h, const float* heat, const float* paf, int mem, int N, int hs, int ws, int ratio,
+extern "C" int lwp_poses_from_maps(lwp_handle h, const float* heat, const float* paf, int mem, int layout, int N, int hs, int ws, int ratio,
                                    int demo, int* kpt_counts, double* kpts, int kpt_cap, double* entries, int entry_cap,
                                    int* n_entries) {
     if (!h || !heat || !paf || !kpt_counts || !kpts || !entries || !n_entries || N <= 0 || hs <= 0 || ws <= 0)
         return fail(h, LWP_ERR_ARG, "bad argument");
     if (ratio != 4 && ratio != 8 && ratio != 1) return fail(h, LWP_ERR_ARG, "upsample ratio must be 1, 4 or 8");
+    if (layout != LWP_LAYOUT_NCHW && layout != LWP_LAYOUT_NHWC) return fail(h, LWP_ERR_ARG, "layout must be LWP_LAYOUT_NCHW or LWP_LAYOUT_NHWC");
     if (h->g.NH < 18 || h->g.NP < 38) return fail(h, LWP_ERR_ARG, "pose grouping needs >= 18 heat-maps and >= 38 PAFs");
     if ((int64_t)hs * ratio > 65535 || (int64_t)ws * ratio > 65535) return fail(h, LWP_ERR_ARG, "map too large");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -918,6 +919,10 @@ extern "C" int lwp_poses_from_maps(lwp_handle h, const float* heat, const float*
     const int64_t hw = (int64_t)hs * ws;
     MapView hv{d_heat, (int64_t)h->g.NH * hw, (int64_t)ws, 1, hw, hs, ws};
     MapView pv{d_paf, (int64_t)h->g.NP * hw, (int64_t)ws, 1, hw, hs, ws};
+    if (layout == LWP_LAYOUT_NHWC) {                 // the averaged maps of val.infer are H x W x C
+        hv.ys = (int64_t)ws * h->g.NH; hv.xs = h->g.NH; hv.cs = 1;
+        pv.ys = (int64_t)ws * h->g.NP; pv.xs = h->g.NP; pv.cs = 1;
+    }
     LAUNCH(h, KC_POST, launch_find_peaks(hv, N, 18, ratio, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_nms(N, 18, hs * ratio, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_score_pairs(pv, N, ratio, demo, h->ws, h->stream));

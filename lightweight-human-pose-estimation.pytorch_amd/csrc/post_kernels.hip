@@ -128,12 +128,14 @@ void build_resize_table(int n_src, int n_dst, std::vector<int>& idx, std::vector
     }
 }
 
-__global__ void __launch_bounds__(256) resize_accum_kernel(const float* src, int Ws, int C, int crop_top, int crop_left,
+__global__ void __launch_bounds__(256) resize_accum_kernel(const float* src, int64_t src_frame, int Ws, int C, int crop_top, int crop_left,
                                                             const int* xi, const float* xw, const int* yi, const float* yw,
                                                             int dst_h, int dst_w, float divisor, float* accum) {
     const int64_t total = (int64_t)dst_h * dst_w * C;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
+    src += (int64_t)blockIdx.y * src_frame;          // one grid row per frame
+    accum += (int64_t)blockIdx.y * total;
     const int c = (int)(idx % C);
     const int x = (int)((idx / C) % dst_w);
     const int y = (int)(idx / ((int64_t)C * dst_w));
@@ -154,11 +156,11 @@ __global__ void __launch_bounds__(256) resize_accum_kernel(const float* src, int
     }
     accum[idx] = __fadd_rn(accum[idx], __fdiv_rn(o, divisor));
 }
-hipError_t launch_resize_accum(const float* src, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,
+hipError_t launch_resize_accum(const float* src, int N, int Hs, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,
                                const int* yi, const float* yw, int dst_h, int dst_w, float divisor, float* accum, hipStream_t s) {
     const int64_t total = (int64_t)dst_h * dst_w * C;
-    hipLaunchKernelGGL(resize_accum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, Ws, C, crop_top, crop_left,
-                       xi, xw, yi, yw, dst_h, dst_w, divisor, accum);
+    hipLaunchKernelGGL(resize_accum_kernel, dim3((unsigned)((total + 255) / 256), N), dim3(256), 0, s, src, (int64_t)Hs * Ws * C, Ws, C,
+                       crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, accum);
     return hipGetLastError();
 }
 

@@ -146,8 +146,8 @@ class Engine(object):
         return x, scale, pad
 
     def multiscale_accumulate(self, accum, maps, up_ratio, pad, n_scales):
-        """accum (H,W,C) float32 [numpy or cuda tensor, updated in place] += resize(crop(upsample(maps))) / n_scales
-        (val.py:96-101).  maps: (1,C,h,w) or (C,h,w) float32 numpy / cuda tensor."""
+        """accum (H,W,C) or (N,H,W,C) float32 [numpy or cuda tensor, updated in place] += resize(crop(upsample(maps))) / n_scales
+        (val.py:96-101).  maps: (C,h,w) or (N,C,h,w) float32 numpy / cuda tensor; the N frames share pad and size."""
         def ptr_mem(a):
             if getattr(a, "is_cuda", False):
                 return a.data_ptr(), MEM_DEVICE
@@ -157,16 +157,23 @@ class Engine(object):
             _torch().cuda.current_stream(maps.device).synchronize()
         else:
             maps = np.ascontiguousarray(maps, dtype=np.float32)
-        shp = tuple(maps.shape)[-3:]
-        H, W, Cc = tuple(accum.shape)
-        if Cc != shp[0]:
+        shp = tuple(maps.shape)
+        ashp = tuple(accum.shape)
+        N = shp[0] if len(shp) == 4 else 1
+        if len(ashp) not in (3, 4) or (len(ashp) == 4 and ashp[0] != N) or (len(ashp) == 3 and N != 1):
+            raise ValueError("accum / maps batch mismatch")
+        H, W, Cc = ashp[-3:]
+        if Cc != shp[-3]:
             raise ValueError("channel mismatch")
-        if not getattr(accum, "is_cuda", False) and (accum.dtype != np.float32 or not accum.flags.c_contiguous):
+        if getattr(accum, "is_cuda", False):
+            if not accum.is_contiguous() or accum.dtype != _torch().float32:
+                raise TypeError("accum must be a contiguous float32 tensor")
+        elif accum.dtype != np.float32 or not accum.flags.c_contiguous:
             raise TypeError("accum must be a C-contiguous float32 array")
         mp, mm = ptr_mem(maps)
         ap, am = ptr_mem(accum)
         padv = (C.c_int * 4)(*[int(v) for v in pad])
-        check(lib().lwp_multiscale_accumulate(self.h.ptr, mp, mm, shp[0], shp[1], shp[2], up_ratio, padv, H, W, n_scales, ap, am), self.h.ptr)
+        check(lib().lwp_multiscale_accumulate(self.h.ptr, mp, mm, N, shp[-3], shp[-2], shp[-1], up_ratio, padv, H, W, n_scales, ap, am), self.h.ptr)
         return accum
 
     def extract_keypoints(self, heatmap):
@@ -231,13 +238,24 @@ class Engine(object):
                                     ent.ctypes.data, ecap, ne.ctypes.data_as(C.POINTER(C.c_int))), self.h.ptr)
         return self._unpack(N, counts, kpts, ent, ne)
 
-    def poses_from_maps(self, heat_nchw, paf_nchw, upsample_ratio=4, demo=True):
-        """Post-processing only, from low-res stage outputs (N,19,h,w) / (N,38,h,w) float32 numpy."""
-        heat = np.ascontiguousarray(heat_nchw, dtype=np.float32)
-        paf = np.ascontiguousarray(paf_nchw, dtype=np.float32)
-        N, _, hs, ws = heat.shape
+    def poses_from_maps(self, heat, paf, upsample_ratio=4, demo=True, layout="NCHW"):
+        """Post-processing only.  layout "NCHW": the low-res stage outputs (N,19,h,w) / (N,38,h,w); layout "NHWC": full-res
+        averaged maps (N,H,W,19) / (N,H,W,38) of the multi-scale path with upsample_ratio=1.  float32 numpy or cuda tensors."""
+        lay = {"NCHW": 0, "NHWC": 1}[layout]
+        if getattr(heat, "is_cuda", False):
+            heat, paf = heat.detach().contiguous(), paf.detach().contiguous()
+            _torch().cuda.current_stream(heat.device).synchronize()
+            hp, pp, mem = heat.data_ptr(), paf.data_ptr(), MEM_DEVICE
+        else:
+            heat = np.ascontiguousarray(heat, dtype=np.float32)
+            paf = np.ascontiguousarray(paf, dtype=np.float32)
+            hp, pp, mem = heat.ctypes.data, paf.ctypes.data, MEM_HOST
+        if lay == 0:
+            N, _, hs, ws = heat.shape
+        else:
+            N, hs, ws, _ = heat.shape
         counts, kpts, ent, ne, kcap, ecap = self._result_buffers(N)
-        check(lib().lwp_poses_from_maps(self.h.ptr, heat.ctypes.data, paf.ctypes.data, MEM_HOST, N, hs, ws, upsample_ratio,
+        check(lib().lwp_poses_from_maps(self.h.ptr, hp, pp, mem, lay, N, hs, ws, upsample_ratio,
                                         1 if demo else 0, counts.ctypes.data_as(C.POINTER(C.c_int)), kpts.ctypes.data, kcap,
                                         ent.ctypes.data, ecap, ne.ctypes.data_as(C.POINTER(C.c_int))), self.h.ptr)
         return self._unpack(N, counts, kpts, ent, ne)

@@ -80,3 +80,49 @@ def infer(net, img, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(
         eng.multiscale_accumulate(avg_heatmaps, stages_output[-2], stride, pad, len(scales_ratios))
         eng.multiscale_accumulate(avg_pafs, stages_output[-1], stride, pad, len(scales_ratios))
     return avg_heatmaps.cpu().numpy(), avg_pafs.cpu().numpy()
+
+
+def scaled_inputs(imgs, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
+    """Host side of val.py:84-93 for a batch of same-sized frames: per scale the float32 (N,3,H',W') network input
+    and its pad [top, left, bottom, right]."""
+    height = imgs[0].shape[0]
+    out = []
+    for ratio in [scale * base_height / float(height) for scale in scales]:
+        xs, pad = [], None
+        for img in imgs:
+            scaled_img = resize_cubic_float(normalize(img, img_mean, img_scale), ratio)
+            min_dims = [base_height, max(scaled_img.shape[1], base_height)]
+            padded_img, pad = pad_width(scaled_img, stride, pad_value, min_dims)
+            xs.append(padded_img.transpose(2, 0, 1))
+        out.append((np.ascontiguousarray(np.stack(xs), dtype=np.float32), pad))
+    return out
+
+
+def accumulate_scales(net, inputs, height, width, stride):
+    """Device side of val.py:94-108 for a batch: inputs = [(x (N,3,H',W') cuda tensor, pad), ...] -> averaged maps
+    (N,height,width,19) and (N,height,width,38) float32 cuda tensors."""
+    import torch
+    eng = net.engine
+    dev = torch.device("cuda", eng.device_id)
+    N = int(inputs[0][0].shape[0])
+    avg_heatmaps = torch.zeros((N, height, width, eng.NH), dtype=torch.float32, device=dev)
+    avg_pafs = torch.zeros((N, height, width, eng.NP), dtype=torch.float32, device=dev)
+    for x, pad in inputs:
+        stages_output = net(x)
+        eng.multiscale_accumulate(avg_heatmaps, stages_output[-2], stride, pad, len(inputs))
+        eng.multiscale_accumulate(avg_pafs, stages_output[-1], stride, pad, len(inputs))
+    return avg_heatmaps, avg_pafs
+
+
+def infer_batch(net, imgs, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
+    """``infer`` (val.py:81-110) for N same-sized frames at once; returns cuda tensors (N,H,W,19), (N,H,W,38)."""
+    import torch
+    dev = torch.device("cuda", net.engine.device_id)
+    inputs = [(torch.from_numpy(x).to(dev), pad) for x, pad in scaled_inputs(imgs, scales, base_height, stride, pad_value, img_mean, img_scale)]
+    return accumulate_scales(net, inputs, imgs[0].shape[0], imgs[0].shape[1], stride)
+
+
+def poses_batch(net, avg_heatmaps, avg_pafs):
+    """val.py:129-134 for a batch on the device: extract_keypoints over the 18 key-point maps + group_keypoints
+    (demo=False rounding) -> per frame (pose_entries (P,20), all_keypoints (K,4), type_counts)."""
+    return net.engine.poses_from_maps(avg_heatmaps, avg_pafs, 1, demo=False, layout="NHWC")

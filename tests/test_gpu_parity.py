@@ -483,6 +483,36 @@ def test_val_infer_multiscale_matches_oracle():
     assert np.abs(got_h - ref_h).max() <= 2e-3 and np.abs(got_p - ref_p).max() <= 2e-3
 
 
+def test_multiscale_batch_equals_per_frame_and_poses_from_hwc_maps():
+    """Config-4 device path: infer_batch == per-frame val.infer (same kernels, batched), and the batched full-resolution
+    NHWC post-processing (demo=False rounding) == the oracle's extract_keypoints + group_keypoints on the same maps."""
+    from lwpose_amd.val import infer, infer_batch, poses_batch
+    net, sd = get_net(3, 1)
+    imgs = synth.make_frames(2, 92, 120, seed0=5)
+    bh, bp = infer_batch(net, list(imgs), [0.5, 1.0, 1.5], 184, 8)
+    assert tuple(bh.shape) == (2, 92, 120, 19) and tuple(bp.shape) == (2, 92, 120, 38)
+    for n in range(2):
+        h1, p1 = infer(net, imgs[n], [0.5, 1.0, 1.5], 184, 8)
+        assert np.array_equal(bh[n].cpu().numpy(), h1) and np.array_equal(bp[n].cpu().numpy(), p1)
+    # realistic full-resolution maps (the random net's averaged maps hold no people): N x H x W x C
+    heat, paf, _ = synth.make_pose_maps(4, 96, 160, 33)
+    heat2, paf2, _ = synth.make_pose_maps(3, 96, 160, 34)
+    hh = np.ascontiguousarray(np.stack([heat, heat2]).transpose(0, 2, 3, 1))
+    pp = np.ascontiguousarray(np.stack([paf, paf2]).transpose(0, 2, 3, 1))
+    got = poses_batch(net, torch.from_numpy(hh).cuda(), torch.from_numpy(pp).cuda())
+    assert len(got) == 2
+    for n in range(2):
+        total, by_type = 0, []
+        hm = hh[n].copy()
+        for k in range(18):
+            total += post_ref.extract_keypoints(hm[:, :, k], by_type, total)
+        ref_e, ref_k = post_ref.group_keypoints(by_type, pp[n], demo=False)
+        ge, gk, _ = got[n]
+        assert len(ref_e) >= 2
+        assert np.array_equal(np.asarray(gk).reshape(-1, 4), np.asarray(ref_k).reshape(-1, 4))
+        assert np.array_equal(np.asarray(ge).reshape(-1, 20), np.asarray(ref_e).reshape(-1, 20))
+
+
 # ------------------------------------------------------------------------------------------ u8 pre-processing (demo.py:55-64)
 @pytest.mark.parametrize("H,W,net_h,stride", [(368, 656, 368, 8), (480, 640, 368, 8), (200, 300, 368, 8), (721, 1283, 368, 8),
                                                (1080, 1920, 256, 8), (333, 111, 368, 8), (64, 96, 64, 16)])
