@@ -126,3 +126,51 @@ def poses_batch(net, avg_heatmaps, avg_pafs):
     """val.py:129-134 for a batch on the device: extract_keypoints over the 18 key-point maps + group_keypoints
     (demo=False rounding) -> per frame (pose_entries (P,20), all_keypoints (K,4), type_counts)."""
     return net.engine.poses_from_maps(avg_heatmaps, avg_pafs, 1, demo=False, layout="NHWC")
+
+
+# ---------------------------------------------------------------------------------------------- COCO results
+# slot of each of the 18 network key-points in COCO's 17-key-point order (the neck, index 1, has none)
+_COCO_SLOT = (0, None, 6, 8, 10, 5, 7, 9, 12, 14, 16, 11, 13, 15, 2, 1, 4, 3)
+
+
+def convert_to_coco_format(pose_entries, all_keypoints):
+    """Same contract as the reference's val.convert_to_coco_format (val.py:52-78): per pose a flat list of 17 x
+    (x + 0.5, y + 0.5, visibility) in COCO order (missing key-points stay 0, 0, 0) and the pose score
+    ``entry[18] * max(0, entry[19] - 1)`` (the neck does not count)."""
+    coco_keypoints, scores = [], []
+    for entry in pose_entries:
+        if len(entry) == 0:
+            continue
+        flat = [0] * (17 * 3)
+        for part, slot in enumerate(_COCO_SLOT):
+            if slot is None:
+                continue
+            kpt_id = entry[part]
+            if kpt_id != -1:
+                cx, cy = all_keypoints[int(kpt_id), 0:2]
+                flat[slot * 3:slot * 3 + 3] = [cx + 0.5, cy + 0.5, 1]
+        coco_keypoints.append(flat)
+        scores.append(entry[-2] * max(0, entry[-1] - 1))
+    return coco_keypoints, scores
+
+
+def coco_detections(net, samples, multiscale=False, base_height=368, stride=8):
+    """The detection loop of val.evaluate (val.py:113-147) without the dataset / pycocotools parts: ``samples`` yields
+    dicts with 'file_name' ('<image id>.jpg') and 'img' (uint8 HxWx3); returns the list of COCO result dicts."""
+    scales = [0.5, 1.0, 1.5, 2.0] if multiscale else [1]
+    results = []
+    for sample in samples:
+        file_name, img = sample['file_name'], sample['img']
+        avg_heatmaps, avg_pafs = infer_batch(net, [img], scales, base_height, stride)
+        pose_entries, all_keypoints, _ = poses_batch(net, avg_heatmaps, avg_pafs)[0]
+        coco_keypoints, scores = convert_to_coco_format(pose_entries, all_keypoints)
+        image_id = int(file_name[0:file_name.rfind('.')])
+        for keypoints, score in zip(coco_keypoints, scores):
+            results.append({'image_id': image_id, 'category_id': 1, 'keypoints': [float(v) for v in keypoints], 'score': float(score)})
+    return results
+
+
+def write_detections(output_name, coco_result):
+    import json
+    with open(output_name, 'w') as f:
+        json.dump(coco_result, f, indent=4)

@@ -113,6 +113,19 @@ def test_preprocess_dims_match_the_oracle(H, W, net_h, stride):
     assert (dh, dw) == (int(round(H * scale)), int(round(W * scale)))
 
 
+def test_convert_to_coco_format_matches_reference_outputs():
+    """val.convert_to_coco_format vs the reference's own function run on the reference's grouping results
+    (tests/golden/coco_format.json, generated by oracle/make_golden.py gen_coco_format)."""
+    from lwpose_amd.val import convert_to_coco_format
+    ref = json.load(open(os.path.join(GOLDEN, "coco_format.json")))
+    assert sum(len(v["scores"]) for v in ref.values()) >= 20
+    for name, want in ref.items():
+        g = np.load(os.path.join(GOLDEN, "post_%s.npz" % name))
+        kps, scores = convert_to_coco_format(g["val_entries"], g["val_allk"])
+        assert [[float(v) for v in k] for k in kps] == want["keypoints"]
+        assert [float(v) for v in scores] == want["scores"]
+
+
 def test_one_euro_filter_matches_reference_sequence():
     from lwpose_amd.modules.one_euro_filter import OneEuroFilter
     ref = json.load(open(os.path.join(GOLDEN, "one_euro.json")))
