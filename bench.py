@@ -248,8 +248,29 @@ def main():
                 pk = MFMA_PEAK_TFLOPS[args.dtype]
                 roofs[k] = {"bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk,
                             "traffic": None, "avg_launch_us": ms * 1e3 / nl, "launches": nl, "alg_flops_per_launch": flops / nl}
+        # HBM-side traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs of
+        # this very command line, summarised by tools/pmc_traffic.py with the gfx950 FETCH_SIZE x2 correction).  Counters
+        # cannot be read from inside the process, so the figure is the one measured when profiles/ was last refreshed; it
+        # is attached only when the workload is the one that was profiled.
+        traffic_src = None
+        if (args.batch, args.height, args.width, args.nref, args.dtype) == (1, 368, 656, 1, "fp32"):
+            cand = sorted(p_ for p_ in (os.path.join(ROOT, "profiles", d, "pmc_traffic_b1_fp32.json") for d in
+                                        (os.listdir(os.path.join(ROOT, "profiles")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []))
+                          if os.path.isfile(p_))
+            if cand:
+                try:
+                    pm = json.load(open(cand[-1]))["classes"]
+                    for k in roofs:
+                        if k in pm:
+                            roofs[k]["traffic"] = pm[k]["traffic_bytes_per_launch"]
+                    traffic_src = os.path.relpath(cand[-1], ROOT)
+                except (OSError, ValueError, KeyError):
+                    traffic_src = None
         dominant = max(roofs, key=lambda k: classes[k]["ms"])
-        roof = dict(roofs[dominant], kernel=dominant)
+        roof = dict(roofs[dominant], kernel=dominant, traffic_unit="bytes/launch (fabric-side, incl. Infinity-Cache hits)",
+                    traffic_source=traffic_src)
+        byt_dom = work[dominant][1] / max(classes[dominant]["launches"], 1)
+        roof["alg_bytes_per_launch"] = byt_dom
         out = {
             "metric": "frames/sec end-to-end (net+grouping) at 368px",
             "value": total_frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

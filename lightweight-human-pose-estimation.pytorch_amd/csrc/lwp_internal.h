@@ -106,6 +106,7 @@ struct GemmParams {
     int out_split = 0;
     const float* zeros;              // >= 16 bytes of zeros (source of out-of-image taps)
     int N, H, W, cin_pad, cout, cout_pad, ks, dil, act;
+    int debug = 0;                   // reserved for timing experiments
 };
 struct DwPwParams {
     const float* in; int in_ld;          // depthwise input, NHWC

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <type_traits>
 #include "lwp_internal.h"
 
 namespace lwp {
@@ -179,7 +180,9 @@ hipError_t launch_dw(const DwParams& p, hipStream_t s) {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int BM, int BN, int KS>
+// KSZ = spatial kernel size (1 or 3), a template parameter so that the tap arithmetic folds at compile time and the
+// 1x1 and dense-3x3 launches carry different kernel names in rocprof traces.
+template <int BM, int BN, int KS, int KSZ>
 __global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(GemmParams p) {
     constexpr int WM = BM / 32, WN = BN / 32;
     constexpr int GW = WM * WN;                     // waves per K-slice group
@@ -241,15 +244,18 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(G
     }
 
     const int ksteps_per_tap = p.cin_pad / BK;
-    const int taps = p.ks * p.ks;
+    constexpr int taps = KSZ * KSZ;
     const int nsteps = taps * ksteps_per_tap;
 
-    f32x4 a_reg[A_PER], b_reg[B_PER];
-    auto load_step = [&](int step) {
+    // register staging, two sets: the loads of K step i+2 are issued while step i is multiplied and step i+1 (loaded
+    // one iteration earlier) is written to the other LDS buffer — an L2 round trip under load is longer than one
+    // step's MFMA time, so a single step of look-ahead left every iteration waiting on vmcnt.
+    f32x4 a_reg[2][A_PER], b_reg[2][B_PER];
+    auto load_step = [&](int step, f32x4* ar, f32x4* br) {
         const int tap = step / ksteps_per_tap;
         const int c0 = (step - tap * ksteps_per_tap) * BK;
         int dy = 0, dx = 0;
-        if (p.ks == 3) { dy = (tap / 3 - 1) * p.dil; dx = (tap % 3 - 1) * p.dil; }
+        if (KSZ == 3) { dy = (tap / 3 - 1) * p.dil; dx = (tap % 3 - 1) * p.dil; }
         const int64_t shift = ((int64_t)dy * p.W + dx) * p.in_ld + c0;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
@@ -258,32 +264,34 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(G
             // taps outside the image read a zero page: the select is on the ADDRESS, so the loaded value goes
             // to LDS untouched and its s_waitcnt lands after the MFMA block (latency hidden behind compute)
             const float* src = ok ? p.in + a_base[i] + shift : p.zeros;
-            a_reg[i] = *(const f32x4*)src;
+            ar[i] = *(const f32x4*)src;
         }
         const float* wt = p.w + ((int64_t)tap * p.cout_pad + n0) * p.cin_pad + c0;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) b_reg[i] = *(const f32x4*)(wt + b_off[i]);
+        for (int i = 0; i < B_PER; ++i) br[i] = *(const f32x4*)(wt + b_off[i]);
     };
-    auto store_step = [&](int buf) {
+    auto store_step = [&](int buf, const f32x4* ar, const f32x4* br) {
         float* a = As + buf * BM * LDS_LD;
         float* b = Bs + buf * BN * LDS_LD;
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) *(f32x4*)(a + a_row[i] * LDS_LD + a_col[i]) = a_reg[i];
+        for (int i = 0; i < A_PER; ++i) *(f32x4*)(a + a_row[i] * LDS_LD + a_col[i]) = ar[i];
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) *(f32x4*)(b + b_lds[i]) = b_reg[i];
+        for (int i = 0; i < B_PER; ++i) *(f32x4*)(b + b_lds[i]) = br[i];
     };
 
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int iters = (nsteps + KS - 1) / KS;
-    if (g < nsteps) { load_step(g); store_step(0); }
+    if (g < nsteps) { load_step(g, a_reg[0], b_reg[0]); store_step(0, a_reg[0], b_reg[0]); }
+    if (g + KS < nsteps) load_step(g + KS, a_reg[1], b_reg[1]);
     __syncthreads();
-    for (int it = 0; it < iters; ++it) {
-        const int cur = g + it * KS, nxt = cur + KS;
-        const int buf = it & 1;
-        if (nxt < nsteps) load_step(nxt);
+    // one half-iteration; P (compile-time) is the LDS buffer being multiplied = the register set being refilled
+    auto half = [&](int it, auto P_) {
+        constexpr int P = decltype(P_)::value;
+        const int cur = g + it * KS, n1 = cur + KS, n2 = cur + 2 * KS;
+        if (n2 < nsteps) load_step(n2, a_reg[P], b_reg[P]);
         if (cur < nsteps) {
-            const float* a = As + buf * BM * LDS_LD + (wm * 32 + r) * LDS_LD + 4 * h;
-            const float* b = Bs + buf * BN * LDS_LD + (wn * 32 + r) * LDS_LD + 4 * h;
+            const float* a = As + P * BM * LDS_LD + (wm * 32 + r) * LDS_LD + 4 * h;
+            const float* b = Bs + P * BN * LDS_LD + (wn * 32 + r) * LDS_LD + 4 * h;
 #pragma unroll
             for (int s = 0; s < BK / 8; ++s) {
                 const f32x4 av = *(const f32x4*)(a + 8 * s);
@@ -294,8 +302,12 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(G
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
             }
         }
-        if (nxt < nsteps) store_step(buf ^ 1);
+        if (n1 < nsteps) store_step(P ^ 1, a_reg[P ^ 1], b_reg[P ^ 1]);
         __syncthreads();
+    };
+    for (int it = 0; it < iters; it += 2) {
+        half(it, std::integral_constant<int, 0>{});
+        half(it + 1, std::integral_constant<int, 1>{});
     }
 
     if (KS > 1) {   // fixed-order reduction of the K-slice partials through LDS (tiles are dead after the last barrier)
@@ -335,8 +347,8 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(G
     }
 }
 
-template <int BM, int BN, int KS>
-static hipError_t launch_gemm_t(const GemmParams& p, hipStream_t s) {
+template <int BM, int BN, int KS, int KSZ>
+static hipError_t launch_gemm_k(const GemmParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.H * p.W;
     const int64_t tiles = ((M + BM - 1) / BM) * (p.cout_pad / BN);
     constexpr int NT = (BM / 32) * (BN / 32) * KS * 64;
@@ -345,12 +357,194 @@ static hipError_t launch_gemm_t(const GemmParams& p, hipStream_t s) {
     if (red > lds) lds = red;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, KS, KSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, KS>), dim3((unsigned)tiles), dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, KS, KSZ>), dim3((unsigned)tiles), dim3(NT), lds, s, p);
     return hipGetLastError();
+}
+template <int BM, int BN, int KS>
+static hipError_t launch_gemm_t(const GemmParams& p, hipStream_t s) {
+    if (p.ks == 3) return launch_gemm_k<BM, BN, KS, 3>(p, s);
+    if (p.ks == 1) return launch_gemm_k<BM, BN, KS, 1>(p, s);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------- implicit GEMM, wave-private tiles
+// The 32-row configurations used at small M (batch 1: M = 3772 pixels cannot fill the chip with 64-row tiles).
+// Same mathematics and the same fragment layout as gemm_kernel, but every wave stages ITS OWN A (32 pixels x 32 k)
+// and B (32 channels x 32 k) tile in a private LDS slice: DS instructions of one wave execute in order, so the K
+// loop needs no barrier at all (a single LDS buffer suffices: the writes of step i+1 are issued after the reads of
+// step i).  With the shared tiles every iteration ended in a workgroup barrier with all eight waves idle at once
+// (in-kernel cycle stamps: 3400 cycles per K step against 2048 of MFMA issue; 2800 here).  Ablation of this kernel
+// at batch 1 (dense 3x3 128->128, 19.5 us per launch): MFMA-only K loop 8.2 us, memory-only 4.9 us (~21 TB/s of
+// L2 -> CU traffic chip-wide), both 13.4 us, fixed prologue/epilogue/launch 6.1 us.  Variants that did NOT help and
+// were dropped: two-deep register prefetch, a three-stage LDS/fragment pipeline, a phase skew between the two waves
+// of a SIMD, and operands loaded straight into fragment registers (no LDS; 32-byte pieces per lane, 21 us).
+// A is loaded by both N-halves of a K group (the second read hits L1/L2); LDS per workgroup: waves x 9 KiB.
+template <int BN, int KS, int KSZ>
+__global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_wp_kernel(GemmParams p) {
+    constexpr int WN = BN / 32;
+    constexpr int WAVE_FLOATS = 2 * 32 * LDS_LD;            // A tile then B tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = wave / WN, wn = wave % WN;                // K-slice group, N half
+    const int r = lane & 31, h = lane >> 5;
+    float* Aw = smem + wave * WAVE_FLOATS;
+    float* Bw = Aw + 32 * LDS_LD;
+
+    const int M = p.N * p.H * p.W;                          // host guarantees < 2^31
+    const int ntn = p.cout_pad / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / ntn, tile_n = bid % ntn;
+    const int m0 = tile_m * 32;
+    const int n0 = tile_n * BN + wn * 32;                   // first output channel of this wave
+    const int n = n0 + r;
+    const float bias = n < p.cout ? p.bias[n] : 0.f;        // in flight during the K loop
+
+    // staging: 16-byte chunk i of a lane = (row (lane >> 3) + 8 i, columns 4 (lane & 7)..+3) of both tiles
+    const int col = (lane & 7) * 4;
+    int a_y[4], a_x[4], lds_off[4], b_off[4];
+    int64_t a_base[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i;
+        const int m = m0 + row;
+        a_ok[i] = m < M;
+        const int mm = a_ok[i] ? m : 0;
+        const int q = mm / p.W;
+        a_x[i] = mm - q * p.W;
+        a_y[i] = q % p.H;
+        a_base[i] = (int64_t)mm * p.in_ld + col;
+        lds_off[i] = row * LDS_LD + col;
+        b_off[i] = (n0 + row) * p.cin_pad + col;
+    }
+    const int ksteps_per_tap = p.cin_pad / BK;
+    constexpr int taps = KSZ * KSZ;
+    const int nsteps = taps * ksteps_per_tap;
+
+    f32x4 a_reg[4], b_reg[4];
+    auto load_step = [&](int step) {
+        const int tap = step / ksteps_per_tap;
+        const int c0 = (step - tap * ksteps_per_tap) * BK;
+        int dy = 0, dx = 0;
+        if (KSZ == 3) { dy = (tap / 3 - 1) * p.dil; dx = (tap % 3 - 1) * p.dil; }
+        const int64_t shift = ((int64_t)dy * p.W + dx) * p.in_ld + c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+            const bool ok = a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const float* src = ok ? p.in + a_base[i] + shift : p.zeros;       // out-of-image taps read the zero page
+            a_reg[i] = *(const f32x4*)src;
+        }
+        const float* wt = p.w + (int64_t)tap * p.cout_pad * p.cin_pad + c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b_reg[i] = *(const f32x4*)(wt + b_off[i]);
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(Aw + lds_off[i]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(Bw + lds_off[i]) = b_reg[i];
+    };
+
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int iters = (nsteps + KS - 1) / KS;
+    if (g < nsteps) { load_step(g); store_step(); }
+    const float* a = Aw + r * LDS_LD + 4 * h;
+    const float* b = Bw + r * LDS_LD + 4 * h;
+    for (int it = 0; it < iters; ++it) {
+        const int cur = g + it * KS, nxt = cur + KS;
+        if (nxt < nsteps) load_step(nxt);
+        if (cur < nsteps) {
+            f32x4 av[BK / 8], bv[BK / 8];
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) { av[s] = *(const f32x4*)(a + 8 * s); bv[s] = *(const f32x4*)(b + 8 * s); }
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].x, bv[s].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].y, bv[s].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].z, bv[s].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].w, bv[s].w, acc, 0, 0, 0);
+            }
+        }
+        if (nxt < nsteps) store_step();          // after this step's reads in program (= LDS execution) order
+    }
+
+    // residual operand of the K-group-0 waves: issued now, consumed after the reduction
+    float resv[16];
+    const bool has_res = p.res != nullptr && g == 0 && n < p.cout;
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            resv[i] = m < M ? p.res[(int64_t)m * p.res_ld + n] : 0.f;
+        }
+    }
+    if (KS > 1) {   // fixed-order reduction of the K-slice partials through LDS
+        __syncthreads();                            // every wave is done with its tiles: the slices are reused
+        float* red = smem;                          // [KS-1][WN][16][64]
+        if (g > 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(((g - 1) * WN + wn) * 16 + i) * 64 + lane] = acc[i];
+        }
+        __syncthreads();
+        if (g > 0) return;
+#pragma unroll
+        for (int gg = 1; gg < KS; ++gg)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += red[(((gg - 1) * WN + wn) * 16 + i) * 64 + lane];
+    }
+
+    if (n < p.cout) {
+        const int HW = p.H * p.W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (m < M) {
+                float v = apply_act(acc[i] + bias, p.act);
+                if (has_res) v += resv[i];
+                p.out[(int64_t)m * p.out_ld + n] = v;
+                if (p.out_nchw || p.out_nchw2) {         // stage outputs (NCHW); merged heads split at out_split
+                    const int img = m / HW, pix = m - img * HW;
+                    const int c0 = p.out_split > 0 ? p.out_split : p.cout;
+                    if (n < c0) { if (p.out_nchw) p.out_nchw[((int64_t)img * c0 + n) * HW + pix] = v; }
+                    else if (p.out_nchw2) p.out_nchw2[((int64_t)img * (p.cout - c0) + (n - c0)) * HW + pix] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BN, int KS, int KSZ>
+static hipError_t launch_gemm_wp_k(const GemmParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    if (M >= (1ll << 31) - 64) return hipErrorInvalidValue;
+    const int64_t tiles = ((M + 31) / 32) * (p.cout_pad / BN);
+    constexpr int NWV = (BN / 32) * KS;
+    size_t lds = (size_t)NWV * 2 * 32 * LDS_LD * sizeof(float);
+    const size_t red = (size_t)(KS - 1) * (BN / 32) * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_wp_kernel<BN, KS, KSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_wp_kernel<BN, KS, KSZ>), dim3((unsigned)tiles), dim3(NWV * 64), lds, s, p);
+    return hipGetLastError();
+}
+template <int BN, int KS>
+static hipError_t launch_gemm_wp_t(const GemmParams& p, hipStream_t s) {
+    if (p.ks == 3) return launch_gemm_wp_k<BN, KS, 3>(p, s);
+    if (p.ks == 1) return launch_gemm_wp_k<BN, KS, 1>(p, s);
+    return hipErrorInvalidValue;
 }
 
 struct GemmCfg { int bm, bn, ks; };
@@ -360,6 +554,12 @@ static bool parse_cfg(const char* env, GemmCfg* c) {
 }
 
 static hipError_t dispatch_gemm(const GemmParams& p, hipStream_t s, GemmCfg c) {
+    static const char* wp_env = getenv("LWP_GEMM_WP");     // "0": shared-tile kernel for the 32-row configurations too (A/B)
+    if (c.bm == 32 && !(wp_env && wp_env[0] == '0')) {
+#define WP_CASE(BN_, KS_) if (c.bn == BN_ && c.ks == KS_) return launch_gemm_wp_t<BN_, KS_>(p, s);
+        WP_CASE(64, 1) WP_CASE(64, 2) WP_CASE(64, 4) WP_CASE(32, 4) WP_CASE(32, 8)
+#undef WP_CASE
+    }
 #define GEMM_CASE(BM_, BN_, KS_) \
     if (c.bm == BM_ && c.bn == BN_ && c.ks == KS_) return launch_gemm_t<BM_, BN_, KS_>(p, s);
     GEMM_CASE(32, 64, 1) GEMM_CASE(32, 64, 2) GEMM_CASE(32, 64, 4)

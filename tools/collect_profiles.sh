@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects everything profiles/<round>/ holds, on the GPU box:  bash tools/collect_profiles.sh gpurun_out/<round>
+# (run through gpurun from the repo root; copy the directory into profiles/ afterwards)
+set -e -o pipefail
+OUT=${1:-gpurun_out/profiles}
+ROOT=$(pwd)
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs"
+# 1. kernel trace + stats of the default bench configuration (two streams) and of the single-stream run
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/rp_default -- $B > $ROOT/$OUT/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/rp_single -- $B --streams 1 > $ROOT/$OUT/bench_under_rocprof_single_stream.json 2>/dev/null
+cp $ROOT/$OUT/rp_default/*/*_kernel_stats.csv $ROOT/$OUT/kernel_stats_b1_fp32_two_streams.csv
+cp $ROOT/$OUT/rp_single/*/*_kernel_stats.csv $ROOT/$OUT/kernel_stats_b1_fp32_single_stream.csv
+rm -rf $ROOT/$OUT/rp_default $ROOT/$OUT/rp_single
+# 2. HBM-side traffic counters, one pass each (never together with other trace domains)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_fetch -- $B --streams 1 --steps 20 --preroll 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_write -- $B --streams 1 --steps 20 --preroll 0 > /dev/null 2>&1
+cd $ROOT
+python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic_b1_fp32.json "batch=1 368x656 fp32 nref=1, bench.py --streams 1" > /dev/null
+rm -rf $OUT/pmc_fetch $OUT/pmc_write
+# 3. per-launch tables (HIP events) and the un-profiled bench line
+python3 tools/profile_layers.py --batch 1 > $OUT/launch_table_b1_fp32.txt 2>/dev/null
+python3 tools/profile_layers.py --batch 32 > $OUT/launch_table_b32_fp32.txt 2>/dev/null
+python3 tools/profile_layers.py --batch 32 --dtype bf16 > $OUT/launch_table_b32_bf16.txt 2>/dev/null
+python3 bench.py > $OUT/bench_default.json 2>/dev/null
+echo done

@@ -1,4 +1,5 @@
-"""time selected layers under a list of env settings: layer_sweep.py batch dtype 'ENV=V,ENV2=V;...' layer..."""
+"""time selected layers under a list of env settings: layer_sweep.py batch dtype 'ENV=V|ENV2=V;...' layer...
+(assignments of one setting are separated by '|', settings by ';')"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -16,7 +17,7 @@ batch, dtype, cfgs, layers = sys.argv[1], sys.argv[2], sys.argv[3].split(";"), s
 tab = {}
 for cfg in cfgs:
     env = dict(os.environ)
-    for kv in cfg.split(","):
+    for kv in cfg.split("|"):
         if "=" in kv:
             k, v = kv.split("="); env[k] = v
     r = subprocess.run([sys.executable, "-c", CHILD, batch, dtype] + layers, capture_output=True, text=True, env=env, timeout=400)
