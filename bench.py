@@ -122,10 +122,18 @@ def main():
     import lwpose_amd  # noqa: F401
     from lwpose_amd import dist as lwdist, synth, workload
 
+    # LWP_BENCH_DEVICE / LWP_BENCH_BACKEND: rehearsal of the multi-rank path on a one-GPU box (all ranks on one card,
+    # gloo instead of RCCL); the driver's runs use one GPU per rank and "nccl" (= RCCL over xGMI)
+    if os.environ.get("LWP_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["LWP_BENCH_DEVICE"])
+    backend = os.environ.get("LWP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            torch.distributed.init_process_group(backend)
 
     # weights: rank 0 builds + calibrates, then ONE RCCL broadcast of the packed blob (no per-step comms)
     net, sd = lwdist.build_replicated_net(args.nref, 1, local_rank, args.dtype, args.height, args.width, rank, world)
@@ -344,8 +352,9 @@ def main():
             except Exception as e:                    # a measurement of a secondary config must not take the bench line down
                 other["batch32_nref3_multiscale_fp32"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["other_configs"] = other
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()              # rank 0 is still measuring its extra figures: leave together
         torch.distributed.destroy_process_group()
 
 
