@@ -737,27 +737,28 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
                         const int v = u * 8 + j * 2 + t;
                         const float b = bcur[v >> 2][v & 3];
 #pragma unroll
-                        for (int a = 0; a < RT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], b, acc[a][t], 0, 0, 0);
+                        // weights are the A operand (rows = channels), activations the B operand (columns = pixels): a lane ends
+                        // up with 4 CONSECUTIVE CHANNELS of one pixel -> 16-byte stores, full 128-byte lines per pixel and wave
+                        for (int a = 0; a < RT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, av[a][j], acc[a][t], 0, 0, 0);
                     }
                 }
             }
         }
     }
-    // epilogue: D layout col = lane&15, row = (lane>>4)*4 + reg
+    // epilogue: D layout row (channel) = (lane>>4)*4 + reg, col (pixel) = lane&15
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int n = wave * 32 + t * 16 + r16;
-        const float bias = p.pw_b[n];
+        const int n = wave * 32 + t * 16 + 4 * q;
+        const f32x4 bias = *(const f32x4*)(p.pw_b + n);
 #pragma unroll
         for (int a = 0; a < RT; ++a) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t m = m0 + a * 16 + q * 4 + g;
-                if (m < M) {
-                    float v = apply_act(acc[a][t][g] + bias, p.act_pw);
-                    if (p.res) v += p.res[m * p.res_ld + n];
-                    p.out[m * p.out_ld + n] = v;
-                }
+            const int64_t m = m0 + a * 16 + r16;
+            if (m < M) {
+                f32x4 v = acc[a][t] + bias;
+                v.x = apply_act(v.x, p.act_pw); v.y = apply_act(v.y, p.act_pw);
+                v.z = apply_act(v.z, p.act_pw); v.w = apply_act(v.w, p.act_pw);
+                if (p.res) v += *(const f32x4*)(p.res + m * p.res_ld + n);
+                *(f32x4*)(p.out + m * p.out_ld + n) = v;
             }
         }
     }
