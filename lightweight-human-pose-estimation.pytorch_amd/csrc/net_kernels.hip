@@ -32,19 +32,20 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // 62 % issue stalls in the PMC profile); one thread computes one pixel x all 32 channels with the weights
 // arriving through scalar loads (uniform addresses); results are transposed through LDS so the write-out is
 // 16 bytes per lane on consecutive addresses (4 KiB contiguous per tile row).
-constexpr int ST_TY = 8, ST_TX = 32;
-template <bool BF16>
-__global__ void __launch_bounds__(256) stem_kernel(StemParams p) {
+constexpr int ST_TX = 32;
+template <bool BF16, int ST_TY>
+__global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
+    constexpr int NT = ST_TY * ST_TX;
     constexpr int IR = 2 * ST_TY + 1, IC = 2 * ST_TX + 1;          // 17 x 65 input region per channel
     constexpr int OLD = BF16 ? 20 : 36;                            // staged row stride in dwords (80 B / 144 B)
     __shared__ float s_in[3][IR][IC + 1];
-    __shared__ __attribute__((aligned(16))) float s_out[256 * OLD];
+    __shared__ __attribute__((aligned(16))) float s_out[NT * OLD];
     const int tid = threadIdx.x;
     const int tiles_x = (p.Wo + ST_TX - 1) / ST_TX;
     const int x0 = (blockIdx.x % tiles_x) * ST_TX, y0 = (blockIdx.x / tiles_x) * ST_TY;
     const int n = blockIdx.y;
     const float* in = p.in + (int64_t)n * 3 * p.H * p.W;
-    for (int i = tid; i < 3 * IR * IC; i += 256) {
+    for (int i = tid; i < 3 * IR * IC; i += NT) {
         const int col = i % IC, r = (i / IC) % IR, c = i / (IC * IR);
         const int yi = 2 * y0 - 1 + r, xi = 2 * x0 - 1 + col;
         float v = 0.f;
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) stem_kernel(StemParams p) {
     }
     __syncthreads();
     constexpr int CPP = BF16 ? 4 : 8;                               // 16-byte chunks per pixel
-    for (int qd = tid; qd < 256 * CPP; qd += 256) {
+    for (int qd = tid; qd < NT * CPP; qd += NT) {
         const int pix = qd / CPP, part = qd % CPP;
         const int yo = y0 + pix / ST_TX, xo = x0 + pix % ST_TX;
         if (yo < p.Ho && xo < p.Wo) {
@@ -89,16 +90,21 @@ __global__ void __launch_bounds__(256) stem_kernel(StemParams p) {
     }
 }
 
-hipError_t launch_stem(const StemParams& p, hipStream_t s) {
-    const int tiles = ((p.Wo + ST_TX - 1) / ST_TX) * ((p.Ho + ST_TY - 1) / ST_TY);
-    hipLaunchKernelGGL(stem_kernel<false>, dim3(tiles, p.N), dim3(256), 0, s, p);
+template <bool BF16>
+static hipError_t launch_stem_t(const StemParams& p, hipStream_t s) {
+    // tile height: 8 rows when that still gives every CU several workgroups, else 4 or 2 (batch 1: 253 -> 1012 workgroups)
+    static const char* env = getenv("LWP_STEM_TY");
+    const int tx = (p.Wo + ST_TX - 1) / ST_TX;
+    int ty = ((int64_t)tx * ((p.Ho + 7) / 8) * p.N >= 2048) ? 8 : (((int64_t)tx * ((p.Ho + 3) / 4) * p.N >= 2048) ? 4 : 2);
+    if (env) ty = atoi(env);
+    if (ty == 8) hipLaunchKernelGGL((stem_kernel<BF16, 8>), dim3(tx * ((p.Ho + 7) / 8), p.N), dim3(256), 0, s, p);
+    else if (ty == 4) hipLaunchKernelGGL((stem_kernel<BF16, 4>), dim3(tx * ((p.Ho + 3) / 4), p.N), dim3(128), 0, s, p);
+    else if (ty == 2) hipLaunchKernelGGL((stem_kernel<BF16, 2>), dim3(tx * ((p.Ho + 1) / 2), p.N), dim3(64), 0, s, p);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t launch_stem_bf16(const StemParams& p, hipStream_t s) {
-    const int tiles = ((p.Wo + ST_TX - 1) / ST_TX) * ((p.Ho + ST_TY - 1) / ST_TY);
-    hipLaunchKernelGGL(stem_kernel<true>, dim3(tiles, p.N), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
+hipError_t launch_stem(const StemParams& p, hipStream_t s) { return launch_stem_t<false>(p, s); }
+hipError_t launch_stem_bf16(const StemParams& p, hipStream_t s) { return launch_stem_t<true>(p, s); }
 
 // ---------------------------------------------------------------------------------------- depthwise
 // one thread = PX consecutive output pixels (along x) x 4 channels; the 3 x (PX*stride + 2*dil) input
