@@ -21,7 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float act_f(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
-    if (act == ACT_ELU) return v > 0.0f ? v : expm1f(v);
+    // bf16 path: the result is rounded to 8 significant bits, so the hardware exp (abs error ~1e-7 on (-1, 0]) replaces
+    // expm1f, which cost ~30 us per cpm.trunk block at batch 32
+    if (act == ACT_ELU) return v > 0.0f ? v : __expf(v) - 1.0f;
     return v;
 }
 
