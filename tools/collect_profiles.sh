@@ -19,6 +19,13 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_
 cd $ROOT
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic_b1_fp32.json "batch=1 368x656 fp32 nref=1, bench.py --streams 1" > /dev/null
 rm -rf $OUT/pmc_fetch $OUT/pmc_write
+# 2b. matrix-pipe utilisation (its own pass)
+for cfg in "b1_fp32:--batch 1 --steps 20" "b32_fp32:--batch 32 --steps 4" "b32_bf16:--batch 32 --dtype bf16 --steps 4"; do
+  tag=${cfg%%:*}; fl=${cfg#*:}
+  (cd /tmp && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $ROOT/$OUT/pmc_mfma -- python3 $ROOT/bench.py --streams 1 $fl --warmup 1 --preroll 0 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1)
+  python3 tools/pmc_mfma.py $OUT/pmc_mfma $OUT/mfma_util_$tag.txt "$tag" > /dev/null
+  rm -rf $OUT/pmc_mfma
+done
 # 3. per-launch tables (HIP events) and the un-profiled bench line
 python3 tools/profile_layers.py --batch 1 > $OUT/launch_table_b1_fp32.txt 2>/dev/null
 python3 tools/profile_layers.py --batch 32 > $OUT/launch_table_b32_fp32.txt 2>/dev/null
