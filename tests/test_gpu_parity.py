@@ -552,3 +552,89 @@ def test_infer_fast_from_u8_frame_matches_oracle_pipeline():
     wp = post_ref.upsample_cubic(outs[-1][0].numpy().transpose(1, 2, 0), 4)
     assert scale == s2 and pad == p2 and heat.shape == wh.shape and paf.shape == wp.shape
     assert np.abs(heat - wh).max() <= NET_TOL and np.abs(paf - wp).max() <= NET_TOL
+
+
+# ------------------------------------------------------------------------------------------ BASELINE sizes: size-independent properties
+def _oracle_post(heat_chw, paf_chw, demo=True):
+    hu = post_ref.upsample_cubic(heat_chw.transpose(1, 2, 0), 4)
+    pu = post_ref.upsample_cubic(paf_chw.transpose(1, 2, 0), 4)
+    by_type, total = [], 0
+    for k in range(18):
+        total += post_ref.extract_keypoints(hu[:, :, k], by_type, total)
+    ent, allk = post_ref.group_keypoints(by_type, pu, demo=demo)
+    return np.asarray(ent, dtype=np.float64).reshape(-1, 20), np.asarray(allk, dtype=np.float64).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_batch32_full_size_determinism_permutation_and_consistency(dtype):
+    """BASELINE configs 2/3 at their full size (32 x 368 x 656): the run is deterministic, permuting the frames of the
+    batch permutes the results bit for bit, a frame's maps do not depend on its batch neighbours beyond the
+    summation-order difference of the tile configurations, and two frames are checked against the oracle
+    (network tolerance; grouping bit-exact on the GPU's own maps)."""
+    from lwpose_amd import workload
+    net, sd = workload.build_net(nref=1, seed=1, device=0, dtype=dtype)
+    x = torch.from_numpy(net_input(32, 368, 656, seed=300)).cuda()
+    eng_ = net.engine
+    r1 = eng_.infer_poses(x, 4, demo=True)
+    r2 = eng_.infer_poses(x, 4, demo=True)
+    perm = torch.arange(31, -1, -1)
+    r3 = eng_.infer_poses(x[perm].contiguous(), 4, demo=True)
+    assert len(r1) == 32 and sum(len(r[0]) for r in r1) >= 64
+    for f in range(32):
+        for a, b in zip(r1[f], r2[f]):
+            assert np.array_equal(a, b)
+        for a, b in zip(r1[f], r3[31 - f]):
+            assert np.array_equal(a, b)
+    outs = [o.cpu().numpy() for o in net(x)]
+    single = [o.cpu().numpy() for o in net(x[7:8].contiguous())]
+    tol_b = 2e-4 if dtype == "fp32" else 0.15
+    for o, s1 in zip(outs, single):
+        assert np.abs(o[7:8] - s1).max() <= tol_b * max(1.0, float(np.abs(s1).max()))
+    if dtype == "fp32":
+        ref = net_ref.forward(sd, x[[0, 31]].cpu(), 1)
+        for o, r in zip(outs, ref):
+            assert np.abs(o[[0, 31]] - r.numpy()).max() <= NET_TOL
+    for f in (0, 31):
+        ent, allk = _oracle_post(outs[-2][f], outs[-1][f])
+        e, a, _ = r1[f]
+        assert np.array_equal(a, allk) and np.array_equal(e.reshape(-1, 20), ent)
+
+
+def test_large_and_tiny_frames():
+    """Edge sizes: a 1080 x 1920 frame (the maps stay below the 65535 limit of the packed peak keys) and the smallest
+    accepted frame (8 x 8 -> 1 x 1 maps, nothing to group) against the oracle."""
+    net, sd = get_net(1, 5)
+    x = net_input(1, 1080, 1920, seed=41)
+    outs = net(x)
+    ref = net_ref.forward(sd, torch.from_numpy(x), 1)
+    assert outs[-1].shape == (1, 38, 135, 240)
+    for o, r in zip(outs, ref):
+        assert np.abs(o - r.numpy()).max() <= NET_TOL
+    heat, paf, _ = synth.make_pose_maps(8, 135, 240, 43)            # people at that map size (the random net's maps are noise)
+    res = net.engine.poses_from_maps(heat[None], paf[None], 4, True)
+    ent, allk = _oracle_post(heat, paf)
+    assert len(ent) >= 4
+    assert np.array_equal(res[0][1], allk) and np.array_equal(res[0][0].reshape(-1, 20), ent)
+    xt = net_input(3, 8, 8, seed=42)
+    outs = net(xt)
+    ref = net_ref.forward(sd, torch.from_numpy(xt), 1)
+    assert outs[-2].shape == (3, 19, 1, 1)
+    for o, r in zip(outs, ref):
+        assert np.abs(o - r.numpy()).max() <= NET_TOL
+    res = net.engine.infer_poses(xt, 4, demo=True)
+    for f in range(3):
+        ent, allk = _oracle_post(outs[-2][f], outs[-1][f])
+        assert np.array_equal(res[f][1], allk) and np.array_equal(res[f][0].reshape(-1, 20), ent)
+
+
+def test_multiscale_full_size_nref3_matches_oracle():
+    """BASELINE config 4 geometry on one full-size frame: 3 refinement stages, scales [0.5, 1.0, 1.5] of base height 368
+    (inputs 368x368, 368x656, 552x984) against the oracle driver (val.py:81-110)."""
+    from lwpose_amd.val import infer
+    from oracle import preproc_ref
+    net, sd = get_net(3, 1)
+    img = synth.make_frames(1, 368, 656, seed0=77)[0]
+    got_h, got_p = infer(net, img, [0.5, 1.0, 1.5], 368, 8)
+    ref_h, ref_p = preproc_ref.infer(sd, 3, img, [0.5, 1.0, 1.5], 368, 8)
+    assert got_h.shape == (368, 656, 19) and got_p.shape == (368, 656, 38)
+    assert np.abs(got_h - ref_h).max() <= 2e-3 and np.abs(got_p - ref_p).max() <= 2e-3
