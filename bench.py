@@ -29,34 +29,75 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}
 
 
+def layer_class(l):
+    """Kernel family of a layer — each family is one kernel (template) name in a rocprof trace."""
+    if l["kind"] == 0:
+        return "stem"
+    if l["kind"] == 3:
+        return "fused_dw_pw"
+    if l["kind"] == 1:
+        return "depthwise"
+    return "gemm_1x1" if l["ksize"] == 1 else "dense_3x3"
+
+
+# kernel-name fragments of every family (rocprofv3 kernel_stats rows are matched with these)
+KERNEL_NAMES = {"stem": ("stem_kernel",), "fused_dw_pw": ("dwpw_kernel", "dwpw_bf16_kernel"), "depthwise": ("dw_kernel",),
+                "gemm_1x1": ("gemm_wp_kernel", "gemm_kernel", "gemm_bf16_kernel"), "dense_3x3": ("gemm_wp_kernel", "gemm_kernel", "gemm_bf16_kernel")}
+
+
 def layer_work(layers, N, H, W, elt_bytes=4):
-    """Algorithmic FLOPs (2*MAC) and bytes (in + out + weights at the storage dtype) per layer class."""
+    """Algorithmic FLOPs (2*MAC) and bytes (in + out + weights at the storage dtype) per kernel family."""
     h, w = H, W
-    acc = {"stem": [0.0, 0.0], "depthwise": [0.0, 0.0], "pointwise_1x1": [0.0, 0.0], "dense_3x3": [0.0, 0.0]}
+    acc = {k: [0.0, 0.0] for k in ("stem", "depthwise", "fused_dw_pw", "gemm_1x1", "dense_3x3")}
     for l in layers:
         hi, wi = h, w
         if l["stride"] == 2:
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         m_out = N * h * w
-        if l["kind"] == 0:
-            k = "stem"
+        k = layer_class(l)
+        if k == "stem":
             flops = 2.0 * m_out * 27 * 32
             byt = (N * hi * wi * 3 + m_out * 32) * 4 + 27 * 32 * 4
-        elif l["kind"] == 3:       # fused depthwise -> pointwise: charged to the (MFMA-bound) 1x1 class with both ops' FLOPs
-            k = "pointwise_1x1"
+        elif k == "fused_dw_pw":   # depthwise 3x3 + pointwise 1x1 in one launch: both ops' FLOPs, block input + output + weights
             flops = 2.0 * m_out * l["macs_per_pixel"]
             byt = (N * hi * wi * l["cin"] + m_out * l["cout"] + 9 * l["cin"] + l["cin"] * l["cout"]) * elt_bytes
-        elif l["kind"] == 1:
-            k = "depthwise"
+        elif k == "depthwise":
             flops = 2.0 * m_out * 9 * l["cin"]
             byt = (N * hi * wi * l["cin"] + m_out * l["cout"] + 9 * l["cin"]) * elt_bytes
         else:
-            k = "pointwise_1x1" if l["ksize"] == 1 else "dense_3x3"
             flops = 2.0 * m_out * l["macs_per_pixel"]        # merged heads: zero blocks are not counted
             byt = (m_out * (l["cin"] + l["cout"]) + l["cin"] * l["cout"] * l["ksize"] ** 2) * elt_bytes
         acc[k][0] += flops
         acc[k][1] += byt
     return acc
+
+
+def rocprof_average_us(family, dtype):
+    """Launch-weighted average duration of the family's kernels in the committed single-stream rocprofv3 summary
+    (profiles/*/kernel_stats_b1_fp32_single_stream.csv) — shown beside the live HIP-event figure."""
+    import csv
+    import re
+    root = os.path.join(ROOT, "profiles")
+    cands = sorted(os.path.join(root, d, "kernel_stats_b1_fp32_single_stream.csv") for d in (os.listdir(root) if os.path.isdir(root) else []))
+    cands = [c for c in cands if os.path.isfile(c)]
+    if not cands or dtype != "fp32":
+        return None, None
+    tot_ns, calls, names = 0.0, 0, []
+    for row in csv.DictReader(open(cands[-1])):
+        nm = row["Name"]
+        if not any(frag + "<" in nm for frag in KERNEL_NAMES[family]):
+            continue
+        if family in ("gemm_1x1", "dense_3x3"):
+            m = re.search(r"<([^>]*)>", nm)
+            last = m.group(1).split(",")[-1].strip() if m else ""
+            if last != ("3" if family == "dense_3x3" else "1"):
+                continue
+        tot_ns += float(row["TotalDurationNs"])
+        calls += int(row["Calls"])
+        names.append(re.sub(r"^void\s+|lwp::|\(.*$", "", nm))
+    if not calls:
+        return None, None
+    return tot_ns / calls / 1e3, {"source": os.path.relpath(cands[-1], ROOT), "kernels": names}
 
 
 def cpu_baseline(sd, x, nref, budget_s=20.0):
@@ -232,16 +273,23 @@ def main():
         engines[:] = saved
         dev_ms = eng.time_pipeline(x, 20, what=1) / 20.0
         net_ms = eng.time_pipeline(x, 20, what=0) / 20.0
-        classes = eng.profile_classes(x, reps=10)
-        # HIP events around EVERY launch add a roughly constant gap per launch; the un-instrumented pipeline time
-        # (events around 20 whole passes) is the ground truth for the sum, so the per-launch overhead is
-        # (sum of per-launch event times - pipeline time) / launches, and it is removed from every class.
+        # HIP events around EVERY launch of a pass (lwp_profile_launches), grouped into kernel families.  The events add a
+        # roughly constant gap per launch; the un-instrumented pipeline time (events around 20 whole passes) is the ground
+        # truth for the sum, so the per-launch overhead is (sum of per-launch times - pipeline time) / launches and it
+        # is removed from every launch.
+        layers = eng.layers()
+        fam = {l["name"]: layer_class(l) for l in layers}
+        classes = {k: {"ms": 0.0, "launches": 0} for k in ("stem", "depthwise", "fused_dw_pw", "gemm_1x1", "dense_3x3", "post")}
+        for name, _, ms in eng.profile_launches(x, reps=10):
+            c = classes[fam.get(name, "post")]
+            c["ms"] += ms
+            c["launches"] += 1
         n_launch = sum(v["launches"] for v in classes.values())
         ev_overhead_ms = max(sum(v["ms"] for v in classes.values()) - dev_ms, 0.0) / max(n_launch, 1)
         for v in classes.values():
             v["ms_raw"] = v["ms"]
             v["ms"] = max(v["ms"] - ev_overhead_ms * v["launches"], 0.0)
-        work = layer_work(eng.layers(), args.batch, args.height, args.width, 4 if args.dtype == "fp32" else 2)
+        work = layer_work(layers, args.batch, args.height, args.width, 4 if args.dtype == "fp32" else 2)
         roofs = {}
         for k, (flops, byt) in work.items():
             ms, nl = classes[k]["ms"], max(classes[k]["launches"], 1)
@@ -275,8 +323,9 @@ def main():
                 except (OSError, ValueError, KeyError):
                     traffic_src = None
         dominant = max(roofs, key=lambda k: classes[k]["ms"])
+        rp_us, rp_src = rocprof_average_us(dominant, args.dtype) if (args.batch, args.height, args.width, args.nref) == (1, 368, 656, 1) else (None, None)
         roof = dict(roofs[dominant], kernel=dominant, traffic_unit="bytes/launch (fabric-side, incl. Infinity-Cache hits)",
-                    traffic_source=traffic_src)
+                    traffic_source=traffic_src, rocprof_avg_launch_us=rp_us, rocprof=rp_src)
         byt_dom = work[dominant][1] / max(classes[dominant]["launches"], 1)
         roof["alg_bytes_per_launch"] = byt_dom
         out = {

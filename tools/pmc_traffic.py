@@ -21,13 +21,13 @@ def kernel_class(name):
     if "stem" in name:
         return "stem"
     if "dwpw" in name:
-        return "pointwise_1x1"
+        return "fused_dw_pw"
     if "gemm" in name:
         m = re.search(r"<([^>]*)>", name)
         args = [a.strip() for a in m.group(1).split(",")] if m else []
         if "bf16" in name:
             return "gemm_bf16"
-        return "dense_3x3" if args and args[-1] == "3" else "pointwise_1x1"
+        return "dense_3x3" if args and args[-1] == "3" else "gemm_1x1"
     if "dw_kernel" in name:
         return "depthwise"
     if any(k in name for k in ("find_peaks", "nms", "score_pairs", "match", "assemble", "publish", "preprocess", "upsample", "resize")):
