@@ -117,7 +117,7 @@ struct DwPwParams {
     const float* res; int res_ld;        // may be null
     const float* zeros;
     int N, Hi, Wi, Ho, Wo, C, cout, stride, dil, act_dw, act_pw;
-    int debug = 0;                       // ablation switches (LWP_DWPW_DEBUG): 1 skip phase 1, 2 skip B loads, 4 skip MFMAs
+    int debug = 0;                       // ablation switches (LWP_DWPW_DEBUG): 1 skip phase 1, 2 skip B loads, 4 skip MFMAs, 8 no XCD tile remap
 };
 bool dwpw_supported(int C, int cout);
 hipError_t launch_dwpw(const DwPwParams& p, hipStream_t s);

@@ -49,7 +49,14 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     const int nwt = gridDim.y * NW;
     const int i16 = lane & 15, q = lane >> 4;
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs): give every XCD a contiguous run of row
+    // blocks, so that the 3-row input windows of neighbouring blocks are fetched into ONE L2 instead of all eight
+    int bid = blockIdx.x;
+    if (gridDim.y == 1) {
+        const int nwg = gridDim.x, qq = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    }
+    const int64_t m0 = (int64_t)bid * BM;
     const int nsteps = p.C / 32;
 
     // weight fragments: PF statically rotated register buffers (K loop unrolled by PF, no copies): PF-1 steps of the
