@@ -382,6 +382,7 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
         GemmParams p;
         p.in = buf_at(h, l.src); p.in_ld = l.src.ld;
         p.w = wts; p.bias = bias;
+        p.wf = h16 ? nullptr : h->d_blob + l.w2_off;
         p.out = dst; p.out_ld = l.dst.ld;
         p.res = l.res.buf >= 0 ? buf_at(h, l.res) : nullptr; p.res_ld = l.res.ld;
         p.out_nchw = (l.out_index >= 0 && d_outs_nchw) ? d_outs_nchw[l.out_index] : nullptr;

@@ -98,6 +98,7 @@ struct DwParams {
 struct GemmParams {
     const float* in; int in_ld;      // window start already applied to the pointer
     const float* w;                  // [taps][cout_pad][cin_pad]
+    const float* wf = nullptr;       // fp32 only: the same weights in fragment order [tap][k-step][32-ch tile][4][64][4]
     const float* bias;               // [cout_pad]
     float* out; int out_ld;
     const float* res; int res_ld;    // may be null

@@ -234,6 +234,10 @@ Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype, bo
             l.cin_pad = round_up(l.cin, h16 ? 64 : 32);
             l.cout_pad = round_up(l.cout, 64);
             l.w_off = off; off += (size_t)l.ks * l.ks * l.cout_pad * l.cin_pad / (h16 ? 2 : 1);
+            if (!h16) {                                       // second copy in MFMA fragment order (32-row tile kernel)
+                off = (off + 63) / 64 * 64;
+                l.w2_off = off; off += (size_t)l.ks * l.ks * l.cout_pad * l.cin_pad;
+            }
         }
         l.b_off = off; off += l.cout_pad;
         off = (off + 63) / 64 * 64;
@@ -328,6 +332,23 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
                         if (g.dtype == LWP_BF16) wh[idx] = f32_to_bf16_rne(v);
                         else wp[idx] = v;
                     }
+        }
+        if (l.kind == L_GEMM && g.dtype != LWP_BF16) {
+            // fragment order for v_mfma_f32_32x32x2_f32 as gemm_wp_kernel walks K: [tap][k-step 32][32-channel tile][s 0..3]
+            // [lane 64][4]: lane (r = lane & 31, h = lane >> 5) holds W[tile*32 + r][step*32 + 8s + 4h + j], j = 0..3, so
+            // one wave-wide 16-byte load is 1 KiB contiguous
+            float* wf = blob.data() + l.w2_off;
+            const int taps = l.ks * l.ks, ksteps = l.cin_pad / 32, ntiles = l.cout_pad / 32;
+            for (int t = 0; t < taps; ++t)
+                for (int ks_ = 0; ks_ < ksteps; ++ks_)
+                    for (int nt = 0; nt < ntiles; ++nt)
+                        for (int sq = 0; sq < 4; ++sq)
+                            for (int ln = 0; ln < 64; ++ln)
+                                for (int j = 0; j < 4; ++j) {
+                                    const size_t src = ((size_t)t * l.cout_pad + nt * 32 + (ln & 31)) * l.cin_pad + ks_ * 32 + 8 * sq + 4 * (ln >> 5) + j;
+                                    const size_t dst = (((((size_t)t * ksteps + ks_) * ntiles + nt) * 4 + sq) * 64 + ln) * 4 + j;
+                                    wf[dst] = wp[src];
+                                }
         }
         if (l.kind == L_DWPW) {
             // pointwise half: (cout, C, 1, 1) -> MFMA fragment order [C/32][cout/32][4][64 lanes][4]; lane (q = lane>>4,

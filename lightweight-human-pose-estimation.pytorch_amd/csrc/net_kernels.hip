@@ -379,26 +379,28 @@ static hipError_t launch_gemm_t(const GemmParams& p, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------- implicit GEMM, wave-private tiles
 // The 32-row configurations used at small M (batch 1: M = 3772 pixels cannot fill the chip with 64-row tiles).
-// Same mathematics and the same fragment layout as gemm_kernel, but every wave stages ITS OWN A (32 pixels x 32 k)
-// and B (32 channels x 32 k) tile in a private LDS slice: DS instructions of one wave execute in order, so the K
-// loop needs no barrier at all (a single LDS buffer suffices: the writes of step i+1 are issued after the reads of
-// step i).  With the shared tiles every iteration ended in a workgroup barrier with all eight waves idle at once
-// (in-kernel cycle stamps: 3400 cycles per K step against 2048 of MFMA issue; 2800 here).  Ablation of this kernel
-// at batch 1 (dense 3x3 128->128, 19.5 us per launch): MFMA-only K loop 8.2 us, memory-only 4.9 us (~21 TB/s of
-// L2 -> CU traffic chip-wide), both 13.4 us, fixed prologue/epilogue/launch 6.1 us.  Variants that did NOT help and
-// were dropped: two-deep register prefetch, a three-stage LDS/fragment pipeline, a phase skew between the two waves
-// of a SIMD, and operands loaded straight into fragment registers (no LDS; 32-byte pieces per lane, 21 us).
-// A is loaded by both N-halves of a K group (the second read hits L1/L2); LDS per workgroup: waves x 9 KiB.
+// Same mathematics and the same fragment layout as gemm_kernel, but every wave stages ITS OWN A tile (32 pixels x 32 k)
+// in a private LDS slice: DS instructions of one wave execute in order, so the K loop needs no barrier at all (one
+// buffer suffices: the writes of step i+1 are issued after the reads of step i).  B never touches LDS: the weights
+// are packed on the host a second time in fragment order, so a K step of a wave is four fully coalesced 1-KiB loads
+// straight into the registers the MFMAs read (double-buffered).  With the shared tiles every iteration ended in a
+// workgroup barrier with all eight waves idle at once (in-kernel cycle stamps: 3400 cycles per K step against 2048
+// of MFMA issue; 2800 here).  Ablation at batch 1 (dense 3x3 128->128, ~19 us per launch): MFMA-only K loop 8.2 us,
+// memory-only 4.9 us (~21 TB/s of L2 -> CU traffic chip-wide), both 13.4 us, fixed prologue/epilogue/launch 6.1 us.
+// Variants that did NOT help and were dropped: two-deep register prefetch, a three-stage LDS/fragment pipeline, a
+// phase skew between the two waves of a SIMD, A loaded straight into fragment registers (32-byte pieces per lane:
+// 21 us).  B through a private LDS tile as well: 19.3 us, this form 18.9 us.
+// A is loaded by both N-halves of a K group (the second read hits L1/L2); LDS per workgroup: waves x 4.5 KiB.
 template <int BN, int KS, int KSZ>
 __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_wp_kernel(GemmParams p) {
     constexpr int WN = BN / 32;
-    constexpr int WAVE_FLOATS = 2 * 32 * LDS_LD;            // A tile then B tile
+    constexpr int WAVE_FLOATS = 32 * LDS_LD;                // the wave's private A tile (B never touches LDS)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave / WN, wn = wave % WN;                // K-slice group, N half
     const int r = lane & 31, h = lane >> 5;
     float* Aw = smem + wave * WAVE_FLOATS;
-    float* Bw = Aw + 32 * LDS_LD;
 
     const int M = p.N * p.H * p.W;                          // host guarantees < 2^31
     const int ntn = p.cout_pad / BN;
@@ -413,9 +415,9 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_wp_kernel(GemmParams
     const int n = n0 + r;
     const float bias = n < p.cout ? p.bias[n] : 0.f;        // in flight during the K loop
 
-    // staging: 16-byte chunk i of a lane = (row (lane >> 3) + 8 i, columns 4 (lane & 7)..+3) of both tiles
+    // A staging: 16-byte chunk i of a lane = (row (lane >> 3) + 8 i, columns 4 (lane & 7)..+3) of the 32 x 32 tile
     const int col = (lane & 7) * 4;
-    int a_y[4], a_x[4], lds_off[4], b_off[4];
+    int a_y[4], a_x[4], lds_off[4];
     int64_t a_base[4];
     bool a_ok[4];
 #pragma unroll
@@ -429,13 +431,15 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_wp_kernel(GemmParams
         a_y[i] = q % p.H;
         a_base[i] = (int64_t)mm * p.in_ld + col;
         lds_off[i] = row * LDS_LD + col;
-        b_off[i] = (n0 + row) * p.cin_pad + col;
     }
     const int ksteps_per_tap = p.cin_pad / BK;
     constexpr int taps = KSZ * KSZ;
     const int nsteps = taps * ksteps_per_tap;
+    // B: the weights in fragment order, [step][32-channel tile][s][lane][4] -> one step of this wave = 4 KiB contiguous
+    const float* b_lane = p.wf + ((int64_t)(n0 >> 5) * 4 * 64 + lane) * 4;
+    const int64_t b_step = (int64_t)(p.cout_pad >> 5) * 4 * 64 * 4;
 
-    f32x4 a_reg[4], b_reg[4];
+    f32x4 a_reg[4], b_nxt[BK / 8];
     auto load_step = [&](int step) {
         const int tap = step / ksteps_per_tap;
         const int c0 = (step - tap * ksteps_per_tap) * BK;
@@ -449,29 +453,32 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_wp_kernel(GemmParams
             const float* src = ok ? p.in + a_base[i] + shift : p.zeros;       // out-of-image taps read the zero page
             a_reg[i] = *(const f32x4*)src;
         }
-        const float* wt = p.w + (int64_t)tap * p.cout_pad * p.cin_pad + c0;
+        const float* bs = b_lane + step * b_step;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b_reg[i] = *(const f32x4*)(wt + b_off[i]);
+        for (int s = 0; s < BK / 8; ++s) b_nxt[s] = *(const f32x4*)(bs + s * 256);
     };
     auto store_step = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) *(f32x4*)(Aw + lds_off[i]) = a_reg[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(f32x4*)(Bw + lds_off[i]) = b_reg[i];
     };
 
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int iters = (nsteps + KS - 1) / KS;
-    if (g < nsteps) { load_step(g); store_step(); }
+    f32x4 bv[BK / 8];
+    if (g < nsteps) {
+        load_step(g);
+        store_step();
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) bv[s] = b_nxt[s];
+    }
     const float* a = Aw + r * LDS_LD + 4 * h;
-    const float* b = Bw + r * LDS_LD + 4 * h;
     for (int it = 0; it < iters; ++it) {
         const int cur = g + it * KS, nxt = cur + KS;
         if (nxt < nsteps) load_step(nxt);
         if (cur < nsteps) {
-            f32x4 av[BK / 8], bv[BK / 8];
+            f32x4 av[BK / 8];
 #pragma unroll
-            for (int s = 0; s < BK / 8; ++s) { av[s] = *(const f32x4*)(a + 8 * s); bv[s] = *(const f32x4*)(b + 8 * s); }
+            for (int s = 0; s < BK / 8; ++s) av[s] = *(const f32x4*)(a + 8 * s);
 #pragma unroll
             for (int s = 0; s < BK / 8; ++s) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].x, bv[s].x, acc, 0, 0, 0);
@@ -480,7 +487,11 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_wp_kernel(GemmParams
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].w, bv[s].w, acc, 0, 0, 0);
             }
         }
-        if (nxt < nsteps) store_step();          // after this step's reads in program (= LDS execution) order
+        if (nxt < nsteps) {
+            store_step();                        // after this step's reads in program (= LDS execution) order
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) bv[s] = b_nxt[s];
+        }
     }
 
     // residual operand of the K-group-0 waves: issued now, consumed after the reduction
@@ -534,9 +545,10 @@ static hipError_t launch_gemm_wp_k(const GemmParams& p, hipStream_t s) {
     if (M >= (1ll << 31) - 64) return hipErrorInvalidValue;
     const int64_t tiles = ((M + 31) / 32) * (p.cout_pad / BN);
     constexpr int NWV = (BN / 32) * KS;
-    size_t lds = (size_t)NWV * 2 * 32 * LDS_LD * sizeof(float);
+    size_t lds = (size_t)NWV * 32 * LDS_LD * sizeof(float);
     const size_t red = (size_t)(KS - 1) * (BN / 32) * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
+    if (!p.wf) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_wp_kernel<BN, KS, KSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
