@@ -513,7 +513,7 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_wp_kernel(GemmParams
         }
         __syncthreads();
         if (g > 0) return;
-#pragma unroll
+#pragma unroll 1
         for (int gg = 1; gg < KS; ++gg)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] += red[(((gg - 1) * WN + wn) * 16 + i) * 64 + lane];
@@ -575,7 +575,7 @@ static hipError_t dispatch_gemm(const GemmParams& p, hipStream_t s, GemmCfg c) {
     static const char* wp_env = getenv("LWP_GEMM_WP");     // "0": shared-tile kernel for the 32-row configurations too (A/B)
     if (c.bm == 32 && !(wp_env && wp_env[0] == '0')) {
 #define WP_CASE(BN_, KS_) if (c.bn == BN_ && c.ks == KS_) return launch_gemm_wp_t<BN_, KS_>(p, s);
-        WP_CASE(64, 1) WP_CASE(64, 2) WP_CASE(64, 4) WP_CASE(32, 4) WP_CASE(32, 8)
+        WP_CASE(64, 1) WP_CASE(64, 2) WP_CASE(64, 4) WP_CASE(64, 8) WP_CASE(32, 4) WP_CASE(32, 8)
 #undef WP_CASE
     }
 #define GEMM_CASE(BM_, BN_, KS_) \
