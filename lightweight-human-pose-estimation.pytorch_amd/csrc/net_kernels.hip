@@ -565,6 +565,209 @@ static hipError_t launch_gemm_wp_t(const GemmParams& p, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------------------- implicit GEMM, A resident in LDS
+// 32-row tiles, third form.  K is split over the KS wave groups by 32-CHANNEL BLOCKS (group g owns blocks g, g+KS, ...),
+// and a group walks all taps of a block.  For a dense 3x3 the nine A tiles of one channel block are the same
+// (32 + 2 dil) x 3 pixel window at nine offsets, so the group stages that window ONCE (3 segments of 32 + 2 dil
+// consecutive pixels, 2.75x fewer loads and LDS stores than nine tiles), one barrier, and the K loop is: four
+// ds_read_b128 at a tap-dependent row offset (taps outside the image: the lane reads a zero row instead), four
+// 1-KiB loads of fragment-packed weights (double-buffered in registers), sixteen MFMAs — no LDS store, no barrier, no
+// global A load inside the loop.  1x1 convs stage their (up to four) 32 x 32 tiles the same way.
+template <int BN, int KS, int KSZ>
+__global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_ar_kernel(GemmParams p) {
+    constexpr int WN = BN / 32;
+    constexpr int GT = WN * 64;                             // threads per K group
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int M = p.N * p.H * p.W;                          // host guarantees < 2^31
+    const int ntn = p.cout_pad / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / ntn, tile_n = bid % ntn;
+    const int m0 = tile_m * 32;
+    const int n0 = tile_n * BN + wn * 32;
+    const int n = n0 + r;
+    const float bias = n < p.cout ? p.bias[n] : 0.f;
+
+    const int kpt = p.cin_pad / BK;                         // channel blocks
+    const int nb = g < kpt ? (kpt - g + KS - 1) / KS : 0;   // blocks of this group
+    const int nb_max = (kpt + KS - 1) / KS;
+    const int seg = KSZ == 3 ? 32 + 2 * p.dil : 32;         // rows per segment
+    const int R = KSZ == 3 ? 3 * seg : 32;                  // rows per block
+    float* Ag = smem + (size_t)g * (nb_max * R + 1) * LDS_LD;   // [nb][R][36] + one zero row
+    float* zrow = Ag + (size_t)nb_max * R * LDS_LD;
+
+    // ---- stage the group's A data: chunk = (block j, row, 16-byte column)
+    {
+        const int t = tid - g * GT;                         // thread within the group
+        const int col = (t & 7) * 4;
+        const int total = nb * R;
+        for (int base = 0; base < total; base += 8 * (GT / 8)) {      // 8 independent loads in flight per thread, then the stores
+            f32x4 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ch = base + (t >> 3) + u * (GT / 8);
+                const int chc = ch < total ? ch : 0;
+                const int j = chc / R, row = chc - j * R;
+                int64_t idx;
+                if (KSZ == 3) {
+                    const int sd = row / seg, rw = row - sd * seg;
+                    idx = (int64_t)m0 + (int64_t)(sd - 1) * p.dil * p.W - p.dil + rw;
+                } else {
+                    idx = (int64_t)m0 + row;
+                }
+                const bool ok = ch < total && idx >= 0 && idx < M;
+                const float* src = ok ? p.in + idx * p.in_ld + (g + j * KS) * BK + col : p.zeros;
+                tmp[u] = *(const f32x4*)src;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ch = base + (t >> 3) + u * (GT / 8);
+                if (ch < total) *(f32x4*)(Ag + (size_t)ch * LDS_LD + col) = tmp[u];
+            }
+        }
+        if (t < 9) *(f32x4*)(zrow + 4 * t) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // the lane's pixel and the taps that fall inside the image
+    const int mrow = m0 + r;
+    const bool row_ok = mrow < M;
+    const int mm = row_ok ? mrow : 0;
+    const int qy = mm / p.W;
+    const int x = mm - qy * p.W, y = qy % p.H;
+    unsigned valid = 0;
+#pragma unroll
+    for (int t = 0; t < KSZ * KSZ; ++t) {
+        const int yy = y + (KSZ == 3 ? (t / 3 - 1) * p.dil : 0), xx = x + (KSZ == 3 ? (t % 3 - 1) * p.dil : 0);
+        if (row_ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) valid |= 1u << t;
+    }
+    constexpr int taps = KSZ * KSZ;
+    const int my_steps = nb * taps;
+    // B: fragment order [step = tap * kpt + block][32-channel tile][s][lane][4]
+    const float* b_lane = p.wf + ((int64_t)(n0 >> 5) * 4 * 64 + lane) * 4;
+    const int64_t b_step = (int64_t)(p.cout_pad >> 5) * 4 * 64 * 4;
+    auto load_b = [&](int i, f32x4* dst) {                  // i-th step of this group: block j = i / taps, tap = i % taps
+        const int j = i / taps, tap = i - j * taps;
+        const float* bs = b_lane + (int64_t)(tap * kpt + g + j * KS) * b_step;
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) dst[s] = *(const f32x4*)(bs + s * 256);
+    };
+    f32x4 bv[2][BK / 8];
+    if (my_steps > 0) load_b(0, bv[0]);
+    __syncthreads();                                        // the windows of every group are complete
+
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* a_lane = Ag + (size_t)r * LDS_LD + 4 * h;
+    const float* z_lane = zrow + 4 * h;
+    auto half = [&](int i, auto P_) {
+        constexpr int P = decltype(P_)::value;
+        const int nxt = i + 1 < my_steps ? i + 1 : i;       // past the end: the last step again (no branch in the body)
+        load_b(nxt, bv[P ^ 1]);
+        const int j = i / taps, tap = i - j * taps;
+        int roff = j * R;
+        if (KSZ == 3) roff += (tap / 3) * seg + (tap % 3) * p.dil;     // segment dy, shift dx (the segment starts at -dil)
+        const float* a = (valid >> tap) & 1u ? a_lane + (size_t)roff * LDS_LD : z_lane;
+        f32x4 av[BK / 8];
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) av[s] = *(const f32x4*)(a + 8 * s);
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].x, bv[P][s].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].y, bv[P][s].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].z, bv[P][s].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s].w, bv[P][s].w, acc, 0, 0, 0);
+        }
+    };
+    int i = 0;
+    for (; i + 1 < my_steps; i += 2) {
+        half(i, std::integral_constant<int, 0>{});
+        half(i + 1, std::integral_constant<int, 1>{});
+    }
+    if (i < my_steps) half(i, std::integral_constant<int, 0>{});
+
+    // residual operand of the K-group-0 waves: requested now, consumed after the reduction
+    float resv[16];
+    const bool has_res = p.res != nullptr && g == 0 && n < p.cout;
+    if (has_res) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            resv[e] = m < M ? p.res[(int64_t)m * p.res_ld + n] : 0.f;
+        }
+    }
+    if (KS > 1) {   // fixed-order reduction of the K-slice partials through LDS
+        __syncthreads();                            // every wave is done with the windows: the space is reused
+        float* red = smem;                          // [KS-1][WN][16][64]
+        if (g > 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(((g - 1) * WN + wn) * 16 + e) * 64 + lane] = acc[e];
+        }
+        __syncthreads();
+        if (g > 0) return;
+#pragma unroll 1
+        for (int gg = 1; gg < KS; ++gg)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += red[(((gg - 1) * WN + wn) * 16 + e) * 64 + lane];
+    }
+
+    if (n < p.cout) {
+        const int HW = p.H * p.W;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < M) {
+                float v = apply_act(acc[e] + bias, p.act);
+                if (has_res) v += resv[e];
+                p.out[(int64_t)m * p.out_ld + n] = v;
+                if (p.out_nchw || p.out_nchw2) {         // stage outputs (NCHW); merged heads split at out_split
+                    const int img = m / HW, pix = m - img * HW;
+                    const int c0 = p.out_split > 0 ? p.out_split : p.cout;
+                    if (n < c0) { if (p.out_nchw) p.out_nchw[((int64_t)img * c0 + n) * HW + pix] = v; }
+                    else if (p.out_nchw2) p.out_nchw2[((int64_t)img * (p.cout - c0) + (n - c0)) * HW + pix] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BN, int KS, int KSZ>
+static hipError_t launch_gemm_ar_k(const GemmParams& p, hipStream_t s, bool* fits) {
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    *fits = false;
+    if (M >= (1ll << 31) - 64 || !p.wf) return hipSuccess;
+    const int kpt = p.cin_pad / BK, nb_max = (kpt + KS - 1) / KS;
+    const int R = KSZ == 3 ? 3 * (32 + 2 * p.dil) : 32;
+    size_t lds = (size_t)KS * ((size_t)nb_max * R + 1) * LDS_LD * sizeof(float);
+    const size_t red = (size_t)(KS - 1) * (BN / 32) * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    if (lds > 150 * 1024) return hipSuccess;                 // caller falls back to the per-step staging kernel
+    *fits = true;
+    constexpr int NWV = (BN / 32) * KS;
+    const int64_t tiles = ((M + 31) / 32) * (p.cout_pad / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_ar_kernel<BN, KS, KSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_ar_kernel<BN, KS, KSZ>), dim3((unsigned)tiles), dim3(NWV * 64), lds, s, p);
+    return hipGetLastError();
+}
+template <int BN, int KS>
+static hipError_t launch_gemm_ar_t(const GemmParams& p, hipStream_t s, bool* fits) {
+    if (p.ks == 3) return launch_gemm_ar_k<BN, KS, 3>(p, s, fits);
+    if (p.ks == 1) return launch_gemm_ar_k<BN, KS, 1>(p, s, fits);
+    *fits = false;
+    return hipSuccess;
+}
+
 struct GemmCfg { int bm, bn, ks; };
 static bool parse_cfg(const char* env, GemmCfg* c) {
     if (!env) return false;
@@ -573,6 +776,14 @@ static bool parse_cfg(const char* env, GemmCfg* c) {
 
 static hipError_t dispatch_gemm(const GemmParams& p, hipStream_t s, GemmCfg c) {
     static const char* wp_env = getenv("LWP_GEMM_WP");     // "0": shared-tile kernel for the 32-row configurations too (A/B)
+    if (c.bm == 32 && !wp_env) {                            // A-resident form when the group windows fit in LDS
+        bool fits = false;
+        hipError_t e = hipSuccess;
+#define AR_CASE(BN_, KS_) if (c.bn == BN_ && c.ks == KS_) e = launch_gemm_ar_t<BN_, KS_>(p, s, &fits);
+        AR_CASE(64, 1) AR_CASE(64, 2) AR_CASE(64, 4) AR_CASE(32, 4) AR_CASE(32, 8)
+#undef AR_CASE
+        if (e != hipSuccess || fits) return e;
+    }
     if (c.bm == 32 && !(wp_env && wp_env[0] == '0')) {
 #define WP_CASE(BN_, KS_) if (c.bn == BN_ && c.ks == KS_) return launch_gemm_wp_t<BN_, KS_>(p, s);
         WP_CASE(64, 1) WP_CASE(64, 2) WP_CASE(64, 4) WP_CASE(64, 8) WP_CASE(32, 4) WP_CASE(32, 8)
