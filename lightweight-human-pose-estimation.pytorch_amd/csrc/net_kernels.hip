@@ -573,6 +573,9 @@ static hipError_t launch_gemm_wp_t(const GemmParams& p, hipStream_t s) {
 // ds_read_b128 at a tap-dependent row offset (taps outside the image: the lane reads a zero row instead), four
 // 1-KiB loads of fragment-packed weights (double-buffered in registers), sixteen MFMAs — no LDS store, no barrier, no
 // global A load inside the loop.  1x1 convs stage their (up to four) 32 x 32 tiles the same way.
+#ifndef AR_PF
+#define AR_PF 2
+#endif
 template <int BN, int KS, int KSZ>
 __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_ar_kernel(GemmParams p) {
     constexpr int WN = BN / 32;
@@ -659,17 +662,19 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_ar_kernel(GemmParams
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) dst[s] = *(const f32x4*)(bs + s * 256);
     };
-    f32x4 bv[2][BK / 8];
-    if (my_steps > 0) load_b(0, bv[0]);
+    constexpr int PF = AR_PF;                               // weight steps in flight per wave (register ring, static indices)
+    f32x4 bv[PF][BK / 8];
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u) load_b(u < my_steps ? u : (my_steps > 0 ? my_steps - 1 : 0), bv[u]);
     __syncthreads();                                        // the windows of every group are complete
 
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float* a_lane = Ag + (size_t)r * LDS_LD + 4 * h;
     const float* z_lane = zrow + 4 * h;
-    auto half = [&](int i, auto P_) {
+    auto one = [&](int i, auto P_) {
         constexpr int P = decltype(P_)::value;
-        const int nxt = i + 1 < my_steps ? i + 1 : i;       // past the end: the last step again (no branch in the body)
-        load_b(nxt, bv[P ^ 1]);
+        const int nxt = i + PF - 1 < my_steps ? i + PF - 1 : my_steps - 1;   // past the end: the last step again (no branch)
+        load_b(nxt, bv[(P + PF - 1) % PF]);
         const int j = i / taps, tap = i - j * taps;
         int roff = j * R;
         if (KSZ == 3) roff += (tap / 3) * seg + (tap % 3) * p.dil;     // segment dy, shift dx (the segment starts at -dil)
@@ -686,11 +691,15 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_ar_kernel(GemmParams
         }
     };
     int i = 0;
-    for (; i + 1 < my_steps; i += 2) {
-        half(i, std::integral_constant<int, 0>{});
-        half(i + 1, std::integral_constant<int, 1>{});
+    for (; i + PF <= my_steps; i += PF) {
+        one(i, std::integral_constant<int, 0>{});
+        if (PF > 1) one(i + 1, std::integral_constant<int, 1 % PF>{});
+        if (PF > 2) one(i + 2, std::integral_constant<int, 2 % PF>{});
+        if (PF > 3) one(i + 3, std::integral_constant<int, 3 % PF>{});
     }
-    if (i < my_steps) half(i, std::integral_constant<int, 0>{});
+    if (i < my_steps) { one(i, std::integral_constant<int, 0>{}); ++i; }
+    if (PF > 2 && i < my_steps) { one(i, std::integral_constant<int, 1 % PF>{}); ++i; }
+    if (PF > 3 && i < my_steps) { one(i, std::integral_constant<int, 2 % PF>{}); ++i; }
 
     // residual operand of the K-group-0 waves: requested now, consumed after the reduction
     float resv[16];
