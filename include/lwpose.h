@@ -112,9 +112,10 @@ int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, int C, int 
 /* ---- one scale of the multi-scale average: replaces val.py:96-101 / 103-108 (x`up_ratio` cubic up-sampling of one
  *      stage output, crop of the padding pad = [top, left, bottom, right], cubic resize to (dst_w, dst_h),
  *      accum = accum + maps / n_scales).  maps: N x C x hs x ws float32 (mem); accum: N x dst_h x dst_w x C float32 HWC (mem);
- *      the N frames share one geometry (same pad, same destination size). */
+ *      the N frames share one geometry (same pad, same destination size).  init != 0: accum is taken as zero (the first
+ *      scale of val.py:86-87) and need not be initialised by the caller. */
 int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int maps_mem, int N, int C, int hs, int ws, int up_ratio,
-                              const int* pad, int dst_h, int dst_w, int n_scales, float* accum, int accum_mem);
+                              const int* pad, int dst_h, int dst_w, int n_scales, float* accum, int accum_mem, int init);
 
 /* ---- extract_keypoints: replaces modules/keypoints.py:16-48 for one heat-map channel.
  *      heatmap: H x W float32 with row stride `row_stride` and pixel stride `pix_stride` (elements), host.

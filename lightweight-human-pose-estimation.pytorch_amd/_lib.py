@@ -65,7 +65,7 @@ def lib():
     L.lwp_debug_time_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]
     L.lwp_pipeline_submit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lwp_pipeline_fetch.argtypes = [vp, C.c_int, ip, vp, C.c_int, vp, C.c_int, ip]
-    L.lwp_multiscale_accumulate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.lwp_multiscale_accumulate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int]
     dp = C.POINTER(C.c_double)
     L.lwp_preprocess_dims.argtypes = [C.c_int] * 4 + [ip] * 5 + [dp]
     L.lwp_preprocess_u8.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, vp]

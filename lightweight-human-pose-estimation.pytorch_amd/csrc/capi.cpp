@@ -488,7 +488,7 @@ extern "C" int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, 
 
 // ---------------------------------------------------------------------------------------------- multi-scale accumulate
 extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int maps_mem, int N, int C, int hs, int ws, int up_ratio,
-                                         const int* pad, int dst_h, int dst_w, int n_scales, float* accum, int accum_mem) {
+                                         const int* pad, int dst_h, int dst_w, int n_scales, float* accum, int accum_mem, int init) {
     if (!h || !maps || !pad || !accum || N <= 0 || C <= 0 || hs <= 0 || ws <= 0 || dst_h <= 0 || dst_w <= 0 || n_scales <= 0)
         return fail(h, LWP_ERR_ARG, "bad argument");
     if (up_ratio != 4 && up_ratio != 8) return fail(h, LWP_ERR_ARG, "upsample ratio must be 4 or 8");
@@ -511,7 +511,7 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     if (accum_mem == LWP_MEM_HOST) {
         rc = ensure_dev(h, &h->d_maps[0], &h->d_maps_bytes[0], ab);
         if (rc) return rc;
-        HIP_TRY(h, hipMemcpyAsync(h->d_maps[0], accum, ab, hipMemcpyHostToDevice, h->stream));
+        if (!init) HIP_TRY(h, hipMemcpyAsync(h->d_maps[0], accum, ab, hipMemcpyHostToDevice, h->stream));
         d_acc = h->d_maps[0];
     }
     std::vector<int> xi, yi;
@@ -532,7 +532,7 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     HIP_TRY(h, hipMemcpyAsync(d_yw, yw.data(), yw.size() * 4, hipMemcpyHostToDevice, h->stream));
     MapView v{d_src, (int64_t)C * hs * ws, (int64_t)ws, 1, (int64_t)hs * ws, hs, ws};
     LAUNCH(h, KC_POST, launch_upsample(v, N, C, up_ratio, h->d_tmp2, h->stream));
-    LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, N, Hs, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, d_acc, h->stream));
+    LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, N, Hs, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, init ? 1 : 0, d_acc, h->stream));
     if (accum_mem == LWP_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(accum, d_acc, ab, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));      // the host tables go out of scope
     return LWP_OK;

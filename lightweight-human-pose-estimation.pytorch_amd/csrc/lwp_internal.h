@@ -190,7 +190,7 @@ hipError_t launch_preprocess_u8(const PreprocParams& p, hipStream_t s);
 hipError_t launch_publish(int N, PostWorkspace& ws, void* host_block, hipStream_t s);   // used rows -> pinned host block
 void build_resize_table(int n_src, int n_dst, std::vector<int>& idx, std::vector<float>& w);
 hipError_t launch_resize_accum(const float* src, int N, int Hs, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,
-                               const int* yi, const float* yw, int dst_h, int dst_w, float divisor, float* accum, hipStream_t s);
+                               const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum, hipStream_t s);
 hipError_t launch_threshold_inplace(float* map, int64_t n, hipStream_t s);
 hipError_t launch_nchw_from_nhwc(const float* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s);
 

@@ -197,7 +197,7 @@ void build_resize_table(int n_src, int n_dst, std::vector<int>& idx, std::vector
 
 __global__ void __launch_bounds__(256) resize_accum_kernel(const float* src, int64_t src_frame, int Ws, int C, int crop_top, int crop_left,
                                                             const int* xi, const float* xw, const int* yi, const float* yw,
-                                                            int dst_h, int dst_w, float divisor, float* accum) {
+                                                            int dst_h, int dst_w, float divisor, int init, float* accum) {
     const int64_t total = (int64_t)dst_h * dst_w * C;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -221,13 +221,14 @@ __global__ void __launch_bounds__(256) resize_accum_kernel(const float* src, int
         const float t = __fmul_rn(a, yw[y * 4 + k]);
         o = k == 0 ? t : __fadd_rn(o, t);
     }
-    accum[idx] = __fadd_rn(accum[idx], __fdiv_rn(o, divisor));
+    // init: the accumulator starts at zero (val.py:86-87) — the add is kept so that the bits are those of 0 + m / n
+    accum[idx] = __fadd_rn(init ? 0.f : accum[idx], __fdiv_rn(o, divisor));
 }
 hipError_t launch_resize_accum(const float* src, int N, int Hs, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,
-                               const int* yi, const float* yw, int dst_h, int dst_w, float divisor, float* accum, hipStream_t s) {
+                               const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum, hipStream_t s) {
     const int64_t total = (int64_t)dst_h * dst_w * C;
     hipLaunchKernelGGL(resize_accum_kernel, dim3((unsigned)((total + 255) / 256), N), dim3(256), 0, s, src, (int64_t)Hs * Ws * C, Ws, C,
-                       crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, accum);
+                       crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum);
     return hipGetLastError();
 }
 

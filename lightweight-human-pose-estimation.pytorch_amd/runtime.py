@@ -145,9 +145,10 @@ class Engine(object):
             self.synchronize()
         return x, scale, pad
 
-    def multiscale_accumulate(self, accum, maps, up_ratio, pad, n_scales):
+    def multiscale_accumulate(self, accum, maps, up_ratio, pad, n_scales, init=False):
         """accum (H,W,C) or (N,H,W,C) float32 [numpy or cuda tensor, updated in place] += resize(crop(upsample(maps))) / n_scales
-        (val.py:96-101).  maps: (C,h,w) or (N,C,h,w) float32 numpy / cuda tensor; the N frames share pad and size."""
+        (val.py:96-101).  maps: (C,h,w) or (N,C,h,w) float32 numpy / cuda tensor; the N frames share pad and size.
+        init=True: accum is treated as zero (first scale), so it may be uninitialised memory."""
         def ptr_mem(a):
             if getattr(a, "is_cuda", False):
                 return a.data_ptr(), MEM_DEVICE
@@ -173,7 +174,7 @@ class Engine(object):
         mp, mm = ptr_mem(maps)
         ap, am = ptr_mem(accum)
         padv = (C.c_int * 4)(*[int(v) for v in pad])
-        check(lib().lwp_multiscale_accumulate(self.h.ptr, mp, mm, N, shp[-3], shp[-2], shp[-1], up_ratio, padv, H, W, n_scales, ap, am), self.h.ptr)
+        check(lib().lwp_multiscale_accumulate(self.h.ptr, mp, mm, N, shp[-3], shp[-2], shp[-1], up_ratio, padv, H, W, n_scales, ap, am, 1 if init else 0), self.h.ptr)
         return accum
 
     def extract_keypoints(self, heatmap):

@@ -105,12 +105,12 @@ def accumulate_scales(net, inputs, height, width, stride):
     eng = net.engine
     dev = torch.device("cuda", eng.device_id)
     N = int(inputs[0][0].shape[0])
-    avg_heatmaps = torch.zeros((N, height, width, eng.NH), dtype=torch.float32, device=dev)
-    avg_pafs = torch.zeros((N, height, width, eng.NP), dtype=torch.float32, device=dev)
-    for x, pad in inputs:
+    avg_heatmaps = torch.empty((N, height, width, eng.NH), dtype=torch.float32, device=dev)   # zero-initialised by the first scale
+    avg_pafs = torch.empty((N, height, width, eng.NP), dtype=torch.float32, device=dev)
+    for k, (x, pad) in enumerate(inputs):
         stages_output = net(x)
-        eng.multiscale_accumulate(avg_heatmaps, stages_output[-2], stride, pad, len(inputs))
-        eng.multiscale_accumulate(avg_pafs, stages_output[-1], stride, pad, len(inputs))
+        eng.multiscale_accumulate(avg_heatmaps, stages_output[-2], stride, pad, len(inputs), init=(k == 0))
+        eng.multiscale_accumulate(avg_pafs, stages_output[-1], stride, pad, len(inputs), init=(k == 0))
     return avg_heatmaps, avg_pafs
 
 
