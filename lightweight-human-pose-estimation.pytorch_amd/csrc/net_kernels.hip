@@ -824,7 +824,13 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     // to 32x32 tiles with an 8-way split.
     const int64_t t64 = ((M + 63) / 64) * (p.cout_pad / 64);
     const int64_t t32 = ((M + 31) / 32) * (p.cout_pad / 64);
-    if (t64 >= 400) {
+    const int64_t t128 = (p.cout_pad % 128 == 0) ? ((M + 127) / 128) * (p.cout_pad / 128) : 0;
+    // 128 x 128 tiles (16 waves x (32 x 32): half the barriers and LDS bytes per FLOP of 64 x 64) when their count fills
+    // whole rounds of the chip's 512 resident workgroups (2 per CU): 472 tiles (batch 16) gain 6 %, 529 tiles lose 8 %
+    const int64_t rounds128 = (t128 + 511) / 512;
+    if (t128 >= 400 && (t128 >= 2048 || t128 * 5 >= rounds128 * 512 * 4)) {
+        c = GemmCfg{128, 128, 1};
+    } else if (t64 >= 400) {
         c = GemmCfg{64, 64, (t64 < 1024 && nsteps >= 8) ? 2 : 1};
     } else if (p.cout_pad == 64 && nsteps >= 16) {
         c = GemmCfg{32, 32, 8};
