@@ -1044,7 +1044,7 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     // there are many pixels.  (BM*8 depthwise items must fit 2 per thread: BM <= 16*NW.)
     int bm = 16;
     if (M / 16 >= 4096) bm = 32;
-    if (M / 32 >= 4096) bm = 64;
+    if (M / 32 >= 3072) bm = 64;                      // batch 32 at 46 x 82 (3772 blocks of 32): 1-5 % over 32 rows
     int nw_wg = nw;                                  // waves per workgroup (column split = nw / nw_wg)
     static const char* env = getenv("LWP_DWPW_BM");
     static const char* env2 = getenv("LWP_DWPW_NW");
