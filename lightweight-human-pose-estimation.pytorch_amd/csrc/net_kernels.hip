@@ -701,39 +701,48 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_ar_kernel(GemmParams
     if (PF > 2 && i < my_steps) { one(i, std::integral_constant<int, 1 % PF>{}); ++i; }
     if (PF > 3 && i < my_steps) { one(i, std::integral_constant<int, 2 % PF>{}); ++i; }
 
-    // residual operand of the K-group-0 waves: requested now, consumed after the reduction
-    float resv[16];
-    const bool has_res = p.res != nullptr && g == 0 && n < p.cout;
-    if (has_res) {
+    // ---- reduction + epilogue, spread over ALL waves: every K group takes 16 / KS of the 16 accumulator registers
+    // (= 8 / KS... rows) of its N half, sums the KS partials in the fixed order 0, 1, ..., KS-1 and stores those rows.
+    constexpr int EPG = 16 / KS;                    // accumulator registers per group in the epilogue
+    const int e0 = g * EPG;
+    float resv[EPG];
+    const bool has_res = p.res != nullptr && n < p.cout;
+    if (has_res) {                                  // requested now, consumed after the reduction
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int u = 0; u < EPG; ++u) {
+            const int e = e0 + u;
             const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            resv[e] = m < M ? p.res[(int64_t)m * p.res_ld + n] : 0.f;
+            resv[u] = m < M ? p.res[(int64_t)m * p.res_ld + n] : 0.f;
         }
     }
-    if (KS > 1) {   // fixed-order reduction of the K-slice partials through LDS
+    float outv[EPG];
+    if (KS > 1) {
         __syncthreads();                            // every wave is done with the windows: the space is reused
-        float* red = smem;                          // [KS-1][WN][16][64]
-        if (g > 0) {
+        float* red = smem;                          // [KS][WN][16][64]
 #pragma unroll
-            for (int e = 0; e < 16; ++e) red[(((g - 1) * WN + wn) * 16 + e) * 64 + lane] = acc[e];
-        }
+        for (int e = 0; e < 16; ++e) red[((g * WN + wn) * 16 + e) * 64 + lane] = acc[e];
         __syncthreads();
-        if (g > 0) return;
-#pragma unroll 1
-        for (int gg = 1; gg < KS; ++gg)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] += red[(((gg - 1) * WN + wn) * 16 + e) * 64 + lane];
+        for (int u = 0; u < EPG; ++u) {
+            float v = red[((0 * WN + wn) * 16 + e0 + u) * 64 + lane];
+#pragma unroll
+            for (int gg = 1; gg < KS; ++gg) v += red[((gg * WN + wn) * 16 + e0 + u) * 64 + lane];
+            outv[u] = v;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < EPG; ++u) outv[u] = acc[u];
     }
 
     if (n < p.cout) {
         const int HW = p.H * p.W;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int u = 0; u < EPG; ++u) {
+            const int e = e0 + u;
             const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (m < M) {
-                float v = apply_act(acc[e] + bias, p.act);
-                if (has_res) v += resv[e];
+                float v = apply_act(outv[u] + bias, p.act);
+                if (has_res) v += resv[u];
                 p.out[(int64_t)m * p.out_ld + n] = v;
                 if (p.out_nchw || p.out_nchw2) {         // stage outputs (NCHW); merged heads split at out_split
                     const int img = m / HW, pix = m - img * HW;
@@ -754,7 +763,7 @@ static hipError_t launch_gemm_ar_k(const GemmParams& p, hipStream_t s, bool* fit
     const int kpt = p.cin_pad / BK, nb_max = (kpt + KS - 1) / KS;
     const int R = KSZ == 3 ? 3 * (32 + 2 * p.dil) : 32;
     size_t lds = (size_t)KS * ((size_t)nb_max * R + 1) * LDS_LD * sizeof(float);
-    const size_t red = (size_t)(KS - 1) * (BN / 32) * 16 * 64 * sizeof(float);
+    const size_t red = (size_t)KS * (BN / 32) * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
     if (lds > 150 * 1024) return hipSuccess;                 // caller falls back to the per-step staging kernel
     *fits = true;
