@@ -29,7 +29,9 @@ struct lwp_context {
     std::vector<size_t> d_outs_bytes;
     float* d_tmp = nullptr; size_t d_tmp_bytes = 0;     // generic device staging (upsample / extract / group)
     float* d_tmp2 = nullptr; size_t d_tmp2_bytes = 0;
-    float* d_tab = nullptr; size_t d_tab_bytes = 0;     // resize tables
+    float* d_tab = nullptr; size_t d_tab_bytes = 0;     // resize tables (unused since the tables are cached per geometry)
+    struct ResizeTab { int cw, ch, dw, dh; void* d; };   // cubic resize tables of the multi-scale path, kept on the device
+    std::vector<ResizeTab> resize_tabs;                  // (a per-call upload went through SDMA queues: multi-ms stalls on some boxes)
     float* d_img = nullptr; size_t d_img_bytes = 0;     // uint8 frame staging (pre-processing of host frames)
     float* d_pre_tab = nullptr; size_t d_pre_tab_bytes = 0;   // fixed-point resize tables, cached for (pre_H, pre_W, pre_net_h)
     int pre_H = 0, pre_W = 0, pre_net_h = 0;
@@ -168,6 +170,7 @@ extern "C" int lwp_destroy(lwp_handle h) {
     if (h->d_tmp2) (void)hipFree(h->d_tmp2);
     for (float* p : h->d_maps) if (p) (void)hipFree(p);
     if (h->d_tab) (void)hipFree(h->d_tab);
+    for (auto& rt : h->resize_tabs) if (rt.d) (void)hipFree(rt.d);
     if (h->d_img) (void)hipFree(h->d_img);
     if (h->d_pre_tab) (void)hipFree(h->d_pre_tab);
     if (h->d_blob) (void)hipFree(h->d_blob);
@@ -514,27 +517,39 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
         if (!init) HIP_TRY(h, hipMemcpyAsync(h->d_maps[0], accum, ab, hipMemcpyHostToDevice, h->stream));
         d_acc = h->d_maps[0];
     }
-    std::vector<int> xi, yi;
-    std::vector<float> xw, yw;
-    build_resize_table(cw, dst_w, xi, xw);
-    build_resize_table(ch, dst_h, yi, yw);
-    const size_t tb = (xi.size() + yi.size()) * 8;
-    rc = ensure_dev(h, &h->d_tab, &h->d_tab_bytes, tb);
-    if (rc) return rc;
-    char* t = (char*)h->d_tab;
-    int* d_xi = (int*)t; t += xi.size() * 4;
-    float* d_xw = (float*)t; t += xw.size() * 4;
-    int* d_yi = (int*)t; t += yi.size() * 4;
+    // per-geometry tables, uploaded once (blocking copy) and kept: steady-state calls issue no host->device copy
+    const size_t nx = (size_t)dst_w * 4, ny = (size_t)dst_h * 4;
+    void* d_tabs = nullptr;
+    for (const auto& rt : h->resize_tabs)
+        if (rt.cw == cw && rt.ch == ch && rt.dw == dst_w && rt.dh == dst_h) { d_tabs = rt.d; break; }
+    if (!d_tabs) {
+        std::vector<int> xi, yi;
+        std::vector<float> xw, yw;
+        build_resize_table(cw, dst_w, xi, xw);
+        build_resize_table(ch, dst_h, yi, yw);
+        if (h->resize_tabs.size() >= 16) {               // bounded: drop the oldest geometry
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            (void)hipFree(h->resize_tabs.front().d);
+            h->resize_tabs.erase(h->resize_tabs.begin());
+        }
+        HIP_TRY(h, hipMalloc(&d_tabs, (nx + ny) * 8));
+        char* t0 = (char*)d_tabs;
+        HIP_TRY(h, hipMemcpy(t0, xi.data(), nx * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(t0 + nx * 4, xw.data(), nx * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(t0 + nx * 8, yi.data(), ny * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(t0 + nx * 8 + ny * 4, yw.data(), ny * 4, hipMemcpyHostToDevice));
+        h->resize_tabs.push_back({cw, ch, dst_w, dst_h, d_tabs});
+    }
+    char* t = (char*)d_tabs;
+    int* d_xi = (int*)t; t += nx * 4;
+    float* d_xw = (float*)t; t += nx * 4;
+    int* d_yi = (int*)t; t += ny * 4;
     float* d_yw = (float*)t;
-    HIP_TRY(h, hipMemcpyAsync(d_xi, xi.data(), xi.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(d_xw, xw.data(), xw.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(d_yi, yi.data(), yi.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(d_yw, yw.data(), yw.size() * 4, hipMemcpyHostToDevice, h->stream));
     MapView v{d_src, (int64_t)C * hs * ws, (int64_t)ws, 1, (int64_t)hs * ws, hs, ws};
     LAUNCH(h, KC_POST, launch_upsample(v, N, C, up_ratio, h->d_tmp2, h->stream));
     LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, N, Hs, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, init ? 1 : 0, d_acc, h->stream));
     if (accum_mem == LWP_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(accum, d_acc, ab, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));      // the host tables go out of scope
+    HIP_TRY(h, hipStreamSynchronize(h->stream));      // results are complete on return (callers read accum on other streams)
     return LWP_OK;
 }
 

@@ -1049,11 +1049,12 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     p.debug = dbg ? atoi(dbg) : 0;
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     const int nw = p.cout / 32;
-    // rows per workgroup: 16 keeps >= ~1 workgroup per CU at batch 1; larger tiles amortise the weight stream when
-    // there are many pixels.  (BM*8 depthwise items must fit 2 per thread: BM <= 16*NW.)
+    // rows per workgroup: the largest of 64 / 32 / 16 that still leaves ~2-4 workgroups per CU (measured at batch 1:
+    // model.1 (943 blocks of 64) 14.7 -> 12.1 us, model.2/3 (472 blocks of 32) 12.9 -> 10.1 / 14.6 -> 12.7 us; the
+    // 46 x 82 layers (236 blocks of 16) lose with anything larger).  (BM*8 depthwise items must fit 2 per thread.)
     int bm = 16;
-    if (M / 16 >= 4096) bm = 32;
-    if (M / 32 >= 3072) bm = 64;                      // batch 32 at 46 x 82 (3772 blocks of 32): 1-5 % over 32 rows
+    if (M / 32 >= 450) bm = 32;
+    if (M / 64 >= 900) bm = 64;
     int nw_wg = nw;                                  // waves per workgroup (column split = nw / nw_wg)
     static const char* env = getenv("LWP_DWPW_BM");
     static const char* env2 = getenv("LWP_DWPW_NW");
