@@ -24,6 +24,7 @@ struct lwp_context {
     // activations for the current (N, H, W)
     int cur_N = 0, cur_H = 0, cur_W = 0;
     std::vector<float*> bufs;
+    std::vector<size_t> buf_bytes;         // allocated size of each activation buffer (grow-only)
     float* d_in = nullptr; size_t d_in_bytes = 0;
     std::vector<float*> d_outs;            // NCHW staging for host outputs
     std::vector<size_t> d_outs_bytes;
@@ -254,15 +255,24 @@ static void level_dims(int H, int W, int level, int* h, int* w) {
 
 static int ensure_activations(lwp_context* h, int N, int H, int W) {
     if (h->cur_N == N && h->cur_H == H && h->cur_W == W) return LWP_OK;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // Buffers only ever GROW: a caller that alternates shapes (the three scales of val.infer) would otherwise free and
+    // re-allocate gigabytes on every call — hipFree / hipMalloc of that size took up to 600 ms on some boxes.
+    if (h->buf_bytes.size() != h->bufs.size()) h->buf_bytes.assign(h->bufs.size(), 0);
+    bool synced = false;
     for (size_t i = 0; i < h->bufs.size(); ++i) {
-        if (h->bufs[i]) { HIP_TRY(h, hipFree(h->bufs[i])); h->bufs[i] = nullptr; }
         int bh, bw;
         level_dims(H, W, h->g.bufs[i].level, &bh, &bw);
         const size_t bytes = (size_t)N * bh * bw * h->g.bufs[i].channels * (h->dtype == LWP_BF16 ? 2 : 4);
-        HIP_TRY(h, hipMalloc((void**)&h->bufs[i], bytes));
-        // the concat buffer's pad channels must hold finite values (their weights are zero)
-        HIP_TRY(h, hipMemsetAsync(h->bufs[i], 0, bytes, h->stream));
+        if (bytes > h->buf_bytes[i]) {
+            if (!synced) { HIP_TRY(h, hipStreamSynchronize(h->stream)); synced = true; }
+            if (h->bufs[i]) { HIP_TRY(h, hipFree(h->bufs[i])); h->bufs[i] = nullptr; h->buf_bytes[i] = 0; }
+            HIP_TRY(h, hipMalloc((void**)&h->bufs[i], bytes));
+            h->buf_bytes[i] = bytes;
+        }
+        // the concat buffer's pad channels are read (with zero weights) but never written: they must hold finite values,
+        // and a re-used buffer may hold anything at the new geometry's offsets -> cleared, stream-ordered.  Every other
+        // buffer is completely overwritten by its producer before it is read.
+        if (h->g.bufs[i].has_pad) HIP_TRY(h, hipMemsetAsync(h->bufs[i], 0, bytes, h->stream));
     }
     h->cur_N = N; h->cur_H = H; h->cur_W = W;
     return LWP_OK;

@@ -58,6 +58,7 @@ struct Layer {
 struct BufSpec {
     int level;      // spatial level: 1 = H/2, 2 = H/4, 3 = H/8
     int channels;   // capacity in channels per pixel (layers may address it with a smaller ld)
+    bool has_pad = false;   // some channels are never written but read with zero weights (the concat buffer): keep them finite
 };
 
 struct Graph {

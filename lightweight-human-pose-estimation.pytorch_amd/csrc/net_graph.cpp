@@ -119,6 +119,7 @@ Graph build_graph(int nref, int C, int NH, int NP, bool fuse_dwpw, int dtype, bo
     int S0 = b.new_buf(3, C), S1 = b.new_buf(3, C), S2 = b.new_buf(3, C);
     int catc = round_up(C + NH + NP, 64);
     int CAT = b.new_buf(3, catc);
+    g.bufs[CAT].has_pad = true;
     const int H2 = b.new_buf(3, 1024 > 2 * C ? 1024 : 2 * C);   // [heat hidden | paf hidden] of the merged head GEMMs
     g.cat_buf = CAT; g.cat_channels = catc;
 

@@ -24,3 +24,13 @@ for x, pad in ins:
     eng.infer_poses(x[:1])  # warm
     ms = eng.time_pipeline(x, 3, what=0) / 3
     print("forward only", tuple(x.shape), "%.1f ms" % ms)
+# per-call split (find which call is slow on a slow box)
+dev = torch.device("cuda", 0)
+for rep in range(2):
+    ah = torch.empty((B, 368, 656, 19), dtype=torch.float32, device=dev); ap = torch.empty((B, 368, 656, 38), dtype=torch.float32, device=dev)
+    for k, (x, pad) in enumerate(ins):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        outs = net3(x); eng.synchronize(); t1 = time.perf_counter()
+        eng.multiscale_accumulate(ah, outs[-2], 8, pad, 3, init=(k == 0)); t2 = time.perf_counter()
+        eng.multiscale_accumulate(ap, outs[-1], 8, pad, 3, init=(k == 0)); t3 = time.perf_counter()
+        print("rep %d scale %d: net %.1f ms, acc heat %.1f ms, acc paf %.1f ms" % (rep, k, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
