@@ -638,3 +638,20 @@ def test_multiscale_full_size_nref3_matches_oracle():
     ref_h, ref_p = preproc_ref.infer(sd, 3, img, [0.5, 1.0, 1.5], 368, 8)
     assert got_h.shape == (368, 656, 19) and got_p.shape == (368, 656, 38)
     assert np.abs(got_h - ref_h).max() <= 2e-3 and np.abs(got_p - ref_p).max() <= 2e-3
+
+
+def test_alternating_frame_shapes_reuse_buffers_without_side_effects():
+    """The engine's activation buffers only grow; a frame processed after a larger one must give exactly the bits a
+    fresh engine gives (the concat buffer's never-written pad channels are re-cleared at every change of shape)."""
+    sd = synth.make_state_dict(3, seed=9)
+    def fresh():
+        net = PoseEstimationWithMobileNet(num_refinement_stages=3)
+        load_state(net, {"state_dict": sd})
+        return net.eval().cuda()
+    a, b = fresh(), fresh()
+    small, big = net_input(2, 96, 160, seed=1), net_input(1, 368, 656, seed=2)
+    ref_small = a(small)                       # engine a: small only
+    b(big); got_small = b(small)               # engine b: big first, then small in the re-used buffers
+    b(big); got_small2 = b(small)
+    for r, g1, g2 in zip(ref_small, got_small, got_small2):
+        assert np.array_equal(r, g1) and np.array_equal(r, g2)
