@@ -428,12 +428,12 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     } else if (p.cout_pad % 128 == 0 && ((M + 127) / 128) * (p.cout_pad / 128) >= 512) {
         bm = 128; bn = 128; rm = 2; rn = 1;           // 8 waves x (64 x 32): 6-25 % faster than 4 waves x (64 x 64) on every layer at batch 32
     } else if (((M + 127) / 128) * (p.cout_pad / 64) >= 512) {
-        bm = 128; bn = 64; rm = 2; rn = 1;            // 4 waves x (64 x 32), 2x2 wave grid
+        bm = 128; bn = 64; rm = 1; rn = 1;            // 8 waves x (32 x 32): the N = 64 head GEMMs, ~10 % over 4 waves x (64 x 32)
     } else {
         bm = 64; bn = 64; rm = 1; rn = 1;             // 4 waves x (32 x 32): small problems
     }
 #define GH_CASE(BM_, BN_, RM_, RN_) if (bm == BM_ && bn == BN_ && rm == RM_ && rn == RN_) return launch_gemm_bf16_t<BM_, BN_, RM_, RN_>(p, s);
-    GH_CASE(128, 128, 2, 2) GH_CASE(128, 64, 2, 1) GH_CASE(64, 64, 1, 1) GH_CASE(256, 128, 2, 2) GH_CASE(128, 128, 2, 1)
+    GH_CASE(128, 128, 2, 2) GH_CASE(128, 64, 2, 1) GH_CASE(64, 64, 1, 1) GH_CASE(256, 128, 2, 2) GH_CASE(128, 128, 2, 1) GH_CASE(128, 128, 1, 1) GH_CASE(128, 64, 1, 1) GH_CASE(256, 128, 2, 1)
 #undef GH_CASE
     return hipErrorInvalidValue;
 }
