@@ -216,7 +216,7 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
     int bm = 16;
     if (M / 16 >= 2048) bm = 32;
     if (M / 32 >= 2048) bm = 64;
-    if (M / 64 >= 1024 && p.C >= 512) bm = 128;      // long K: halve the per-workgroup weight stream (measured +6 %)
+    if (M / 64 >= 1024 && nw >= 8) bm = 128;         // >= 256 output channels: halve the per-workgroup weight stream (measured 3-8 %)
     static const char* env = getenv("LWP_DWPW_BM");
     if (env) bm = atoi(env);
     while (bm > 16 && (size_t)bm * (p.C + 8) * 2 > 150 * 1024) bm >>= 1;
