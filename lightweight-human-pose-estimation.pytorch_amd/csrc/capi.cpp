@@ -30,7 +30,6 @@ struct lwp_context {
     std::vector<size_t> d_outs_bytes;
     float* d_tmp = nullptr; size_t d_tmp_bytes = 0;     // generic device staging (upsample / extract / group)
     float* d_tmp2 = nullptr; size_t d_tmp2_bytes = 0;
-    float* d_tab = nullptr; size_t d_tab_bytes = 0;     // resize tables (unused since the tables are cached per geometry)
     struct ResizeTab { int cw, ch, dw, dh; void* d; };   // cubic resize tables of the multi-scale path, kept on the device
     std::vector<ResizeTab> resize_tabs;                  // (a per-call upload went through SDMA queues: multi-ms stalls on some boxes)
     float* d_img = nullptr; size_t d_img_bytes = 0;     // uint8 frame staging (pre-processing of host frames)
@@ -170,7 +169,6 @@ extern "C" int lwp_destroy(lwp_handle h) {
     if (h->d_tmp) (void)hipFree(h->d_tmp);
     if (h->d_tmp2) (void)hipFree(h->d_tmp2);
     for (float* p : h->d_maps) if (p) (void)hipFree(p);
-    if (h->d_tab) (void)hipFree(h->d_tab);
     for (auto& rt : h->resize_tabs) if (rt.d) (void)hipFree(rt.d);
     if (h->d_img) (void)hipFree(h->d_img);
     if (h->d_pre_tab) (void)hipFree(h->d_pre_tab);
