@@ -14,7 +14,8 @@
  *     device memory it allocates.  Pointer arguments tagged "mem" accept host or device memory
  *     according to the LWP_MEM_* flag passed with them (device pointers = zero-copy from
  *     torch-ROCm tensors via data_ptr()).
- *   - one handle per (device, stream); a handle is not thread-safe; distinct handles are independent.
+ *   - one handle per (device, stream); a handle is not thread-safe; distinct handles are independent (handles on
+ *     different devices may live in one process; the usual deployment is one process per GPU).
  *   - all maps are float32.  Network tensors crossing the ABI are NCHW (as the reference's
  *     nn.Module sees them); post-processing maps are HWC (as numpy sees them after demo.py:71-76).
  */
@@ -103,6 +104,20 @@ int lwp_preprocess_dims(int H, int W, int net_input_height, int stride, int* sca
                         int* out_h, int* out_w, int* pad, double* scale);
 int lwp_preprocess_u8(lwp_handle h, const unsigned char* img, int img_mem, int H, int W, int net_input_height, int stride,
                       const double* pad_value, const double* img_mean, double img_scale, float* out_device);
+
+/* ---- image side of ONE scale of the multi-scale driver: replaces val.py:84-93 for N same-sized uint8 frames
+ *      (normalize, val.py:30-33: float64 (u8 - mean) * scale;  cv2.resize(normed_img, (0,0), fx=fy=ratio, INTER_CUBIC) on
+ *      the float64 image: float32 cubic coefficients (A = -0.75), float64 left-to-right sums, horizontal pass then vertical
+ *      pass;  pad_width(scaled, stride, pad_value, [base_height, max(scaled_w, base_height)]), val.py:36-49;  HWC -> NCHW
+ *      float32, val.py:93).  lwp_scale_dims is pure host arithmetic: scaled size = round-half-even(H*ratio, W*ratio), the
+ *      padded size out_h x out_w and pad = [top, left, bottom, right] exactly as pad_width returns them.
+ *      lwp_preprocess_scaled_u8: imgs is N x H x W x 3 uint8 (mem), out a DEVICE buffer of N*3*out_h*out_w float32.
+ *      Runs on the handle's stream (the resize tables of a geometry are built once and kept on the device). */
+int lwp_scale_dims(int H, int W, double ratio, int base_height, int stride, int* scaled_h, int* scaled_w,
+                   int* out_h, int* out_w, int* pad);
+int lwp_preprocess_scaled_u8(lwp_handle h, const unsigned char* imgs, int img_mem, int N, int H, int W, double ratio,
+                             int base_height, int stride, const double* pad_value, const double* img_mean, double img_scale,
+                             float* out_device);
 
 /* ---- bicubic up-sampling: replaces cv2.resize(map, (0,0), fx=r, fy=r, INTER_CUBIC) on float maps
  *      (demo.py:72,76; val.py:98,105).  src: N x C x h x w (mem);  dst: N x (h*r) x (w*r) x C (mem). */

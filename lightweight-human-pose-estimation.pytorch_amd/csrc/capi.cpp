@@ -30,8 +30,10 @@ struct lwp_context {
     std::vector<size_t> d_outs_bytes;
     float* d_tmp = nullptr; size_t d_tmp_bytes = 0;     // generic device staging (upsample / extract / group)
     float* d_tmp2 = nullptr; size_t d_tmp2_bytes = 0;
-    struct ResizeTab { int cw, ch, dw, dh; void* d; };   // cubic resize tables of the multi-scale path, kept on the device
+    struct ResizeTab { int cw, ch, dw, dh; void* d; double ratio; };   // cubic resize tables of the multi-scale path, kept on the device
     std::vector<ResizeTab> resize_tabs;                  // (a per-call upload went through SDMA queues: multi-ms stalls on some boxes)
+    std::vector<ResizeTab> scale_tabs;                   // image-side tables of lwp_preprocess_scaled_u8: (W, H, dw, dh, ratio)
+    unsigned char* d_imgs = nullptr; size_t d_imgs_bytes = 0;   // uint8 frame batch staging (host frames of the multi-scale path)
     float* d_img = nullptr; size_t d_img_bytes = 0;     // uint8 frame staging (pre-processing of host frames)
     float* d_pre_tab = nullptr; size_t d_pre_tab_bytes = 0;   // fixed-point resize tables, cached for (pre_H, pre_W, pre_net_h)
     int pre_H = 0, pre_W = 0, pre_net_h = 0;
@@ -115,6 +117,10 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
     *out = nullptr;
     if (nref < 0 || C <= 0 || C % 32 || NH <= 0 || NP <= 0) return fail(nullptr, LWP_ERR_ARG, "bad network shape (num_channels must be a multiple of 32)");
     if (dtype != LWP_F32 && dtype != LWP_BF16) return fail(nullptr, LWP_ERR_ARG, "bad dtype");
+    // the bf16 graph has no stand-alone depthwise kernel and its GEMM walks K in 64-channel steps: cpm.trunk must fuse
+    // (C in {64, 128, 256, 512}); any other width would run f32 kernels on bf16-sized buffers
+    if (dtype == LWP_BF16 && !(C % 64 == 0 && dwpw_supported(C, C)))
+        return fail(nullptr, LWP_ERR_ARG, "bf16 path supports num_channels 64, 128, 256 or 512 only");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, LWP_ERR_NOGPU, "no HIP device available");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, LWP_ERR_ARG, "device_id out of range");
@@ -170,6 +176,8 @@ extern "C" int lwp_destroy(lwp_handle h) {
     if (h->d_tmp2) (void)hipFree(h->d_tmp2);
     for (float* p : h->d_maps) if (p) (void)hipFree(p);
     for (auto& rt : h->resize_tabs) if (rt.d) (void)hipFree(rt.d);
+    for (auto& rt : h->scale_tabs) if (rt.d) (void)hipFree(rt.d);
+    if (h->d_imgs) (void)hipFree(h->d_imgs);
     if (h->d_img) (void)hipFree(h->d_img);
     if (h->d_pre_tab) (void)hipFree(h->d_pre_tab);
     if (h->d_blob) (void)hipFree(h->d_blob);
@@ -546,7 +554,7 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
         HIP_TRY(h, hipMemcpy(t0 + nx * 4, xw.data(), nx * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(t0 + nx * 8, yi.data(), ny * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(t0 + nx * 8 + ny * 4, yw.data(), ny * 4, hipMemcpyHostToDevice));
-        h->resize_tabs.push_back({cw, ch, dst_w, dst_h, d_tabs});
+        h->resize_tabs.push_back({cw, ch, dst_w, dst_h, d_tabs, 0.0});
     }
     char* t = (char*)d_tabs;
     int* d_xi = (int*)t; t += nx * 4;
@@ -627,6 +635,86 @@ extern "C" int lwp_preprocess_u8(lwp_handle h, const unsigned char* img, int img
     p.out = out_device;
     LAUNCH(h, KC_POST, launch_preprocess_u8(p, h->stream));
     if (img_mem == LWP_MEM_HOST) HIP_TRY(h, hipStreamSynchronize(h->stream));   // the caller may reuse its frame buffer
+    return LWP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- multi-scale image side
+extern "C" int lwp_scale_dims(int H, int W, double ratio, int base_height, int stride, int* scaled_h, int* scaled_w,
+                              int* out_h, int* out_w, int* pad) {
+    if (H <= 0 || W <= 0 || !(ratio > 0.0) || base_height <= 0 || stride <= 0 || !scaled_h || !scaled_w || !out_h || !out_w || !pad)
+        return fail(nullptr, LWP_ERR_ARG, "bad argument");
+    const double fw = nearbyint((double)W * ratio), fh = nearbyint((double)H * ratio);   // cv2 dsize: round half to even
+    if (!(fw >= 1.0 && fh >= 1.0 && fw <= 65535.0 && fh <= 65535.0)) return fail(nullptr, LWP_ERR_ARG, "scaled frame is empty or too large");
+    const int dw = (int)fw, dh = (int)fh;
+    // val.py:36-49 with min_dims = [base_height, max(dw, base_height)] (val.py:90)
+    const int hh = dh < base_height ? dh : base_height;
+    const int min0 = (int)ceil(base_height / (double)stride) * stride;
+    const int m1 = dw > base_height ? dw : base_height;
+    const int min1 = (int)ceil(m1 / (double)stride) * stride;
+    pad[0] = (int)floor((min0 - hh) / 2.0);
+    pad[1] = (int)floor((min1 - dw) / 2.0);
+    pad[2] = min0 - hh - pad[0];
+    pad[3] = min1 - dw - pad[1];
+    *scaled_h = dh; *scaled_w = dw;
+    *out_h = dh + pad[0] + pad[2];
+    *out_w = dw + pad[1] + pad[3];
+    return LWP_OK;
+}
+
+extern "C" int lwp_preprocess_scaled_u8(lwp_handle h, const unsigned char* imgs, int img_mem, int N, int H, int W, double ratio,
+                                        int base_height, int stride, const double* pad_value, const double* img_mean,
+                                        double img_scale, float* out_device) {
+    if (!h || !imgs || !pad_value || !img_mean || !out_device || N <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    int dh, dw, Hp, Wp, pad[4];
+    int rc = lwp_scale_dims(H, W, ratio, base_height, stride, &dh, &dw, &Hp, &Wp, pad);
+    if (rc) return fail(h, rc, "bad frame size / scale ratio");
+    if (pad[0] < 0 || pad[1] < 0 || pad[2] < 0 || pad[3] < 0) return fail(h, LWP_ERR_ARG, "negative padding");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const unsigned char* d_src = imgs;
+    if (img_mem == LWP_MEM_HOST) {
+        const size_t ib = (size_t)N * H * W * 3;
+        if (h->d_imgs_bytes < ib) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (h->d_imgs) HIP_TRY(h, hipFree(h->d_imgs));
+            h->d_imgs = nullptr; h->d_imgs_bytes = 0;
+            HIP_TRY(h, hipMalloc((void**)&h->d_imgs, ib));
+            h->d_imgs_bytes = ib;
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_imgs, imgs, ib, hipMemcpyHostToDevice, h->stream));
+        d_src = h->d_imgs;
+    }
+    const size_t nx = (size_t)dw * 4, ny = (size_t)dh * 4;
+    void* d_tabs = nullptr;
+    for (const auto& rt : h->scale_tabs)
+        if (rt.cw == W && rt.ch == H && rt.dw == dw && rt.dh == dh && rt.ratio == ratio) { d_tabs = rt.d; break; }
+    if (!d_tabs) {                                       // per-geometry tables, uploaded once and kept
+        std::vector<int> xi, yi;
+        std::vector<float> xw, yw;
+        build_resize_table_ratio(W, dw, ratio, xi, xw);
+        build_resize_table_ratio(H, dh, ratio, yi, yw);
+        if (h->scale_tabs.size() >= 16) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            (void)hipFree(h->scale_tabs.front().d);
+            h->scale_tabs.erase(h->scale_tabs.begin());
+        }
+        HIP_TRY(h, hipMalloc(&d_tabs, (nx + ny) * 8));
+        char* t0 = (char*)d_tabs;
+        HIP_TRY(h, hipMemcpy(t0, xi.data(), nx * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(t0 + nx * 4, xw.data(), nx * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(t0 + nx * 8, yi.data(), ny * 4, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(t0 + nx * 8 + ny * 4, yw.data(), ny * 4, hipMemcpyHostToDevice));
+        h->scale_tabs.push_back({W, H, dw, dh, d_tabs, ratio});
+    }
+    char* t = (char*)d_tabs;
+    PreScaleParams p;
+    p.src = d_src; p.N = N; p.Hs = H; p.Ws = W;
+    p.xi = (const int*)t; p.xw = (const float*)(t + nx * 4); p.yi = (const int*)(t + nx * 8); p.yw = (const float*)(t + nx * 8 + ny * 4);
+    p.dh = dh; p.dw = dw; p.top = pad[0]; p.left = pad[1]; p.Hp = Hp; p.Wp = Wp;
+    for (int c = 0; c < 3; ++c) { p.mean[c] = img_mean[c]; p.pad_value[c] = (float)pad_value[c]; }
+    p.scale = img_scale;
+    p.out = out_device;
+    LAUNCH(h, KC_POST, launch_preprocess_scaled(p, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));         // out_device is consumed on other streams; host frames may be reused
     return LWP_OK;
 }
 

@@ -188,11 +188,40 @@ struct PreprocParams {
 };
 void build_resize_table_u8(int n_src, int n_dst, double inv_scale, std::vector<int>& idx, std::vector<int>& w);
 hipError_t launch_preprocess_u8(const PreprocParams& p, hipStream_t s);
+// N uint8 frames -> normalised float64 image, cubic resize by a ratio (f32 coefficients, f64 sums), pad, NCHW float32 (val.py:84-93)
+struct PreScaleParams {
+    const unsigned char* src; int N, Hs, Ws;         // N x Hs x Ws x 3 uint8
+    const int *xi, *yi;                              // 4 clamped source indices per destination index
+    const float *xw, *yw;                            // 4 float32 cubic coefficients per destination index
+    int dh, dw, top, left, Hp, Wp;
+    double mean[3], scale;
+    float pad_value[3];
+    float* out;                                      // N x 3 x Hp x Wp
+};
+void build_resize_table_ratio(int n_src, int n_dst, double ratio, std::vector<int>& idx, std::vector<float>& w);
+hipError_t launch_preprocess_scaled(const PreScaleParams& p, hipStream_t s);
 hipError_t launch_publish(int N, PostWorkspace& ws, void* host_block, hipStream_t s);   // used rows -> pinned host block
 void build_resize_table(int n_src, int n_dst, std::vector<int>& idx, std::vector<float>& w);
 hipError_t launch_resize_accum(const float* src, int N, int Hs, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,
                                const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum, hipStream_t s);
 hipError_t launch_threshold_inplace(float* map, int64_t n, hipStream_t s);
 hipError_t launch_nchw_from_nhwc(const float* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: every launcher keeps one flag per device
+// (a process may hold handles on several GPUs; the usual deployment is one process per GPU).
+constexpr int kMaxDevices = 64;
+struct LdsAttrOnce {
+    bool done[kMaxDevices] = {};
+    hipError_t ensure(const void* fn, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+        if (done[dev]) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) done[dev] = true;
+        return e;
+    }
+};
 
 }  // namespace lwp

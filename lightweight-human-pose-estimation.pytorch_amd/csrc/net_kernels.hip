@@ -361,11 +361,10 @@ static hipError_t launch_gemm_k(const GemmParams& p, hipStream_t s) {
     size_t lds = (size_t)KS * 2 * (BM + BN) * LDS_LD * sizeof(float);
     const size_t red = (size_t)(KS - 1) * (BM / 32) * (BN / 32) * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, KS, KSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsAttrOnce attr;
+    if (lds > 64 * 1024) {
+        hipError_t e = attr.ensure((const void*)gemm_kernel<BM, BN, KS, KSZ>, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, KS, KSZ>), dim3((unsigned)tiles), dim3(NT), lds, s, p);
     return hipGetLastError();
@@ -549,11 +548,10 @@ static hipError_t launch_gemm_wp_k(const GemmParams& p, hipStream_t s) {
     const size_t red = (size_t)(KS - 1) * (BN / 32) * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
     if (!p.wf) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_wp_kernel<BN, KS, KSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsAttrOnce attr;
+    if (lds > 64 * 1024) {
+        hipError_t e = attr.ensure((const void*)gemm_wp_kernel<BN, KS, KSZ>, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_wp_kernel<BN, KS, KSZ>), dim3((unsigned)tiles), dim3(NWV * 64), lds, s, p);
     return hipGetLastError();
@@ -769,11 +767,10 @@ static hipError_t launch_gemm_ar_k(const GemmParams& p, hipStream_t s, bool* fit
     *fits = true;
     constexpr int NWV = (BN / 32) * KS;
     const int64_t tiles = ((M + 31) / 32) * (p.cout_pad / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_ar_kernel<BN, KS, KSZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    static LdsAttrOnce attr;
+    {
+        hipError_t e = attr.ensure((const void*)gemm_ar_kernel<BN, KS, KSZ>, 150 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_ar_kernel<BN, KS, KSZ>), dim3((unsigned)tiles), dim3(NWV * 64), lds, s, p);
     return hipGetLastError();
@@ -1029,11 +1026,10 @@ static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     const size_t lds = (size_t)BM * (p.C + 4) * sizeof(float);
     const int nsplit = (p.cout / 32) / NW;
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)dwpw_kernel<BM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsAttrOnce attr;
+    if (lds > 48 * 1024) {
+        hipError_t e = attr.ensure((const void*)dwpw_kernel<BM, NW>, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr = true;
     }
     hipLaunchKernelGGL((dwpw_kernel<BM, NW>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
     return hipGetLastError();

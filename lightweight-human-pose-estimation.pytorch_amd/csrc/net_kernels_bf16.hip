@@ -200,11 +200,10 @@ static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     const size_t lds = (size_t)BM * (p.C + 8) * 2;
     const int nsplit = (p.cout / 32) / NW;
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)dwpw_bf16_kernel<BM, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static LdsAttrOnce attr;
+    if (lds > 48 * 1024) {
+        hipError_t e = attr.ensure((const void*)dwpw_bf16_kernel<BM, NW>, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr = true;
     }
     hipLaunchKernelGGL((dwpw_bf16_kernel<BM, NW>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
@@ -409,11 +408,10 @@ static hipError_t launch_gemm_bf16_t(const GemmParams& p, hipStream_t s) {
     const int64_t tiles = ((M + BM - 1) / BM) * (p.cout_pad / BN);
     constexpr int NT = (BM / (32 * RM)) * (BN / (32 * RN)) * 64;
     const size_t lds = (size_t)2 * (BM + BN) * HLD * 2;
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, RM, RN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsAttrOnce attr;
+    if (lds > 48 * 1024) {
+        hipError_t e = attr.ensure((const void*)gemm_bf16_kernel<BM, BN, RM, RN>, (int)lds);
         if (e != hipSuccess) return e;
-        attr = true;
     }
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, RM, RN>), dim3((unsigned)tiles), dim3(NT), lds, s, p);
     return hipGetLastError();

@@ -320,6 +320,68 @@ hipError_t launch_preprocess_u8(const PreprocParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ multi-scale image side
+// val.py:84-93 on the device for N same-sized uint8 frames and one scale ratio.  The normalised image is float64 in the
+// reference ((float32(u8) - mean) * scale with a Python tuple: NumPy promotes to float64), cv2.resize of a float64 image
+// uses float32 cubic coefficients and float64 sums (horizontal pass, then vertical pass, left to right), pad_width fills a
+// constant border and the tensor handed to the network is float32.  One thread per output pixel (3 channels); the frames
+// stay in L2 (0.7 MB each), the output is written once.
+void build_resize_table_ratio(int n_src, int n_dst, double ratio, std::vector<int>& idx, std::vector<float>& w) {
+    const double scale = 1.0 / ratio;
+    idx.resize((size_t)n_dst * 4);
+    w.resize((size_t)n_dst * 4);
+    for (int d = 0; d < n_dst; ++d) {
+        const float fx = (float)(((double)d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(fx);
+        volatile float frac = fx - (float)s;
+        for (int k = 0; k < 4; ++k) {
+            int j = s - 1 + k;
+            idx[(size_t)d * 4 + k] = j < 0 ? 0 : (j > n_src - 1 ? n_src - 1 : j);
+        }
+        cubic_coeffs_host(frac, &w[(size_t)d * 4]);
+    }
+}
+
+__global__ void __launch_bounds__(256) preprocess_scaled_kernel(PreScaleParams p) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, n = blockIdx.z;
+    if (x >= p.Wp) return;
+    const int yy = y - p.top, xx = x - p.left;
+    const int64_t plane = (int64_t)p.Hp * p.Wp;
+    float* o = p.out + (int64_t)n * 3 * plane + (int64_t)y * p.Wp + x;
+    if (yy < 0 || yy >= p.dh || xx < 0 || xx >= p.dw) {
+        o[0] = p.pad_value[0]; o[plane] = p.pad_value[1]; o[2 * plane] = p.pad_value[2];
+        return;
+    }
+    const unsigned char* img = p.src + (int64_t)n * p.Hs * p.Ws * 3;
+    int xo[4];
+    double wx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { xo[k] = p.xi[xx * 4 + k] * 3; wx[k] = (double)p.xw[xx * 4 + k]; }
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const unsigned char* row = img + (int64_t)p.yi[yy * 4 + ky] * p.Ws * 3;
+        const double wy = (double)p.yw[yy * 4 + ky];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double t = 0.0;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const double v = __dmul_rn(__dsub_rn((double)row[xo[kx] + c], p.mean[c]), p.scale);   // normalize, val.py:30-33
+                const double pr = __dmul_rn(v, wx[kx]);
+                t = kx == 0 ? pr : __dadd_rn(t, pr);
+            }
+            const double q = __dmul_rn(t, wy);
+            acc[c] = ky == 0 ? q : __dadd_rn(acc[c], q);
+        }
+    }
+    o[0] = (float)acc[0]; o[plane] = (float)acc[1]; o[2 * plane] = (float)acc[2];
+}
+hipError_t launch_preprocess_scaled(const PreScaleParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(preprocess_scaled_kernel, dim3((p.Wp + 255) / 256, p.Hp, p.N), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ result hand-over
 // Writes the USED part of the result block (flags, counts, the first `total` key-point rows and the first
 // n_entries pose rows of every frame) straight into pinned host memory at the same offsets, so the host parses

@@ -89,22 +89,37 @@ def get_similarity(a, b, threshold=0.5):
 def track_poses(previous_poses, current_poses, threshold=3, smooth=False):
     """Give every current pose the id of the most similar still-unclaimed previous pose (at least ``threshold``
     similar key-points), most confident poses first; unmatched poses get fresh ids.  With ``smooth`` the matched
-    key-points continue the previous pose's 1-Euro filters."""
-    claimed = [False] * len(previous_poses)
+    key-points continue the previous pose's 1-Euro filters (reference: modules/pose.py:78-118).
+
+    Corner cases kept from the reference: a candidate must have at least ONE similar key-point to be considered (strict
+    ``>`` scan from 0, first maximum wins); with ``threshold <= 0`` and no candidate every previous pose becomes
+    unavailable (NumPy's ``mask[None] = 0``); a matched previous pose whose own id is None hands over neither id nor
+    filters."""
+    free = np.ones(len(previous_poses), dtype=bool)
     for cur in sorted(current_poses, key=lambda p: p.confidence, reverse=True):
-        scores = [0 if claimed[i] else _similar_keypoints(cur, prev) for i, prev in enumerate(previous_poses)]
-        best = int(np.argmax(scores)) if scores else -1          # first maximum, like a strict '>' scan
-        matched = best >= 0 and scores[best] >= threshold and scores[best] > 0
-        if matched:
-            claimed[best] = True
-        cur.update_id(previous_poses[best].id if matched else None)
+        best, best_n = None, 0
+        for i, prev in enumerate(previous_poses):
+            if not free[i]:
+                continue
+            n = _similar_keypoints(cur, prev)
+            if n > best_n:
+                best, best_n = i, n
+        inherited = None
+        if best_n >= threshold:
+            if best is None:
+                free[:] = False
+            else:
+                free[best] = False
+                inherited = previous_poses[best].id
+        cur.update_id(inherited)
         if not smooth:
             continue
+        donor = previous_poses[best] if inherited is not None else None
         for k in range(Pose.num_kpts):
             if cur.keypoints[k, 0] == -1:
                 continue
-            if matched and previous_poses[best].keypoints[k, 0] != -1:
-                cur.filters[k] = previous_poses[best].filters[k]
+            if donor is not None and donor.keypoints[k, 0] != -1:
+                cur.filters[k] = donor.filters[k]
             fx, fy = cur.filters[k]
             cur.keypoints[k, 0] = fx(cur.keypoints[k, 0])
             cur.keypoints[k, 1] = fy(cur.keypoints[k, 1])

@@ -145,6 +145,39 @@ class Engine(object):
             self.synchronize()
         return x, scale, pad
 
+    @staticmethod
+    def scale_dims(height, width, ratio, base_height, stride):
+        """(scaled_h, scaled_w, out_h, out_w, pad [top,left,bottom,right]) of val.py:89-91 for a height x width frame."""
+        v = [C.c_int() for _ in range(4)]
+        pad = (C.c_int * 4)()
+        check(lib().lwp_scale_dims(height, width, float(ratio), base_height, stride, *[C.byref(a) for a in v], pad))
+        return v[0].value, v[1].value, v[2].value, v[3].value, [int(a) for a in pad]
+
+    def preprocess_scaled_u8(self, imgs, ratio, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1 / 256):
+        """N same-sized uint8 frames (N,H,W,3) or one (H,W,3), numpy or cuda tensor -> (x: N x 3 x H' x W' float32 cuda tensor, pad):
+        normalize + cubic resize by ``ratio`` + pad_width of val.py:84-93 in one kernel."""
+        torch = _torch()
+        on_dev = getattr(imgs, "is_cuda", False)
+        a = imgs.contiguous() if on_dev else np.ascontiguousarray(imgs)
+        if (a.dtype != (torch.uint8 if on_dev else np.uint8)) or len(a.shape) not in (3, 4) or a.shape[-1] != 3:
+            raise TypeError("frames must be (N,)HxWx3 uint8")
+        shp = tuple(a.shape) if len(a.shape) == 4 else (1,) + tuple(a.shape)
+        N, H, W = int(shp[0]), int(shp[1]), int(shp[2])
+        _, _, oh, ow, pad = self.scale_dims(H, W, ratio, base_height, stride)
+        if on_dev:
+            if a.device.index != self.device_id:
+                raise ValueError("frames are on cuda:%d but the engine lives on cuda:%d" % (a.device.index, self.device_id))
+            torch.cuda.current_stream(a.device).synchronize()
+            ptr, mem = a.data_ptr(), MEM_DEVICE
+        else:
+            ptr, mem = a.ctypes.data, MEM_HOST
+        x = torch.empty((N, 3, oh, ow), dtype=torch.float32, device=torch.device("cuda", self.device_id))
+        pv = (C.c_double * 3)(*[float(v) for v in pad_value])
+        mv = (C.c_double * 3)(*[float(v) for v in img_mean])
+        check(lib().lwp_preprocess_scaled_u8(self.h.ptr, ptr, mem, N, H, W, float(ratio), base_height, stride, pv, mv, float(img_scale),
+                                             x.data_ptr()), self.h.ptr)
+        return x, pad
+
     def multiscale_accumulate(self, accum, maps, up_ratio, pad, n_scales, init=False):
         """accum (H,W,C) or (N,H,W,C) float32 [numpy or cuda tensor, updated in place] += resize(crop(upsample(maps))) / n_scales
         (val.py:96-101).  maps: (C,h,w) or (N,C,h,w) float32 numpy / cuda tensor; the N frames share pad and size.
@@ -283,7 +316,24 @@ class Engine(object):
         n = dims[0] * dims[1] * dims[2] * dims[3]
         return buf[:n].reshape(dims[0], dims[1], dims[2], dims[3]).copy()
 
+    def _as_device_input(self, x):
+        """Checks shared by every entry point that hands ``data_ptr()`` of a resident frame batch to the library: float32,
+        contiguous, (N,3,H,W), on this engine's GPU; work still queued on torch's current stream is waited for (the
+        library runs on its own non-blocking stream)."""
+        torch = _torch()
+        if not getattr(x, "is_cuda", False):
+            raise TypeError("expected a cuda tensor")
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+            raise TypeError("expected a float32 (N, 3, H, W) tensor, got %s %s" % (x.dtype, tuple(x.shape)))
+        if not x.is_contiguous():
+            raise ValueError("input tensor must be contiguous")
+        if x.device.index != self.device_id:
+            raise ValueError("input is on cuda:%d but the engine lives on cuda:%d" % (x.device.index, self.device_id))
+        torch.cuda.current_stream(x.device).synchronize()
+        return x
+
     def infer_poses_async(self, x_cuda, upsample_ratio=4, demo=True):
+        x_cuda = self._as_device_input(x_cuda)
         N, _, H, W = x_cuda.shape
         self._keep = x_cuda
         check(lib().lwp_infer_poses_async(self.h.ptr, x_cuda.data_ptr(), N, H, W, upsample_ratio, 1 if demo else 0), self.h.ptr)
@@ -298,6 +348,7 @@ class Engine(object):
 
     # ------------------------------------------------------------------ pipelined streaming (two slots)
     def pipeline_submit(self, x_cuda, slot, upsample_ratio=4, demo=True):
+        x_cuda = self._as_device_input(x_cuda)
         N, _, H, W = x_cuda.shape
         self._keep_slot = getattr(self, "_keep_slot", {})
         self._keep_slot[slot] = (x_cuda, N)
@@ -313,6 +364,7 @@ class Engine(object):
     # ------------------------------------------------------------------ measurement
     def time_pipeline(self, x_cuda, iters, what=1, upsample_ratio=4, demo=True):
         """milliseconds for ``iters`` back-to-back passes (HIP events on the engine's stream)."""
+        x_cuda = self._as_device_input(x_cuda)
         N, _, H, W = x_cuda.shape
         ms = C.c_float()
         check(lib().lwp_time_pipeline(self.h.ptr, x_cuda.data_ptr(), N, H, W, upsample_ratio, 1 if demo else 0, what, iters, C.byref(ms)), self.h.ptr)
@@ -326,6 +378,7 @@ class Engine(object):
 
     def profile_launches(self, x_cuda, reps=5, upsample_ratio=4, demo=True):
         """[(name, class, ms)] per launch in issue order (HIP events around every launch)."""
+        x_cuda = self._as_device_input(x_cuda)
         N, _, H, W = x_cuda.shape
         cap = 256
         ms = (C.c_float * cap)()
@@ -338,6 +391,7 @@ class Engine(object):
         return [(names[i] if i < len(names) else "launch%d" % i, kc[i], ms[i]) for i in range(n.value)]
 
     def profile_classes(self, x_cuda, reps=5, upsample_ratio=4, demo=True):
+        x_cuda = self._as_device_input(x_cuda)
         N, _, H, W = x_cuda.shape
         ms = (C.c_float * 6)()
         ln = (C.c_int * 6)()

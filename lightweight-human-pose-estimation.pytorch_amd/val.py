@@ -1,8 +1,10 @@
-"""Host pre-processing helpers with the reference's names and semantics (reference: val.py:30-49).
+"""Drop-ins for the reference's ``val`` helpers (reference: val.py:30-147): ``normalize`` / ``pad_width`` (host, for callers
+that use them directly), the multi-scale driver ``infer`` (all of it on the GPU), ``convert_to_coco_format`` and the
+detection loop.
 
-OpenCV is not a dependency: ``cv2.copyMakeBorder(BORDER_CONSTANT)`` is a constant fill + copy.  The uint8
-``cv2.resize(INTER_CUBIC)`` of demo.py:59 runs on the GPU (``Engine.preprocess_u8``, OpenCV's fixed-point
-algorithm: 11-bit coefficients, A = -0.75) — unpinned against cv2 itself, which is absent from the build container.
+OpenCV is not a dependency: ``cv2.copyMakeBorder(BORDER_CONSTANT)`` is a constant fill + copy.  The cubic resizes
+(uint8 fixed point of demo.py:59, float64 of val.py:89, float32 of val.py:98-107) run on the GPU with OpenCV's published
+algorithms — unpinned against cv2 itself, which is absent from the build container.
 """
 import math
 
@@ -30,72 +32,29 @@ def pad_width(img, stride, pad_value, min_dims):
     return out, pad
 
 
-def _cubic_coeffs_f32(x):
-    f = np.float32
-    x = f(x); A = f(-0.75)
-    c0 = ((A * (x + f(1)) - f(5) * A) * (x + f(1)) + f(8) * A) * (x + f(1)) - f(4) * A
-    c1 = ((A + f(2)) * x - (A + f(3))) * x * x + f(1)
-    c2 = ((A + f(2)) * (f(1) - x) - (A + f(3))) * (f(1) - x) * (f(1) - x) + f(1)
-    return np.array([c0, c1, c2, f(1) - c0 - c1 - c2], dtype=np.float32)
-
-
-def resize_cubic_float(img, ratio):
-    """cv2.resize(img, (0,0), fx=ratio, fy=ratio, interpolation=cv2.INTER_CUBIC) for the float64 normalised image
-    (val.py:89): destination size round(src*ratio), scale 1/ratio, float32 coefficients, float64 sums."""
-    img = np.ascontiguousarray(img, dtype=np.float64)
-    h, w = img.shape[:2]
-    dw, dh = int(round(w * ratio)), int(round(h * ratio))
-
-    def tables(n_src, n_dst):
-        d = np.arange(n_dst)
-        f = ((d + 0.5) * (1.0 / ratio) - 0.5).astype(np.float32)
-        s = np.floor(f).astype(np.int64)
-        frac = f - s.astype(np.float32)
-        idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
-        return idx, np.stack([_cubic_coeffs_f32(t) for t in frac]).astype(np.float64)
-    xi, xw = tables(w, dw)
-    yi, yw = tables(h, dh)
-    t = sum(img[:, xi[:, k]] * xw[None, :, k, None] for k in range(4))
-    return sum(t[yi[:, k]] * yw[:, k, None, None] for k in range(4))
+def _as_u8_frames(imgs):
+    a = np.ascontiguousarray(imgs) if not getattr(imgs, "is_cuda", False) else imgs
+    if (str(a.dtype) not in ("uint8", "torch.uint8")) or len(a.shape) != 4 or a.shape[-1] != 3:
+        raise TypeError("frames must be uint8 (N, H, W, 3) — the multi-scale driver starts from the decoded image (val.py:84)")
+    return a
 
 
 def infer(net, img, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
     """Drop-in for the reference's multi-scale ``val.infer`` (val.py:81-110): returns (avg_heatmaps HxWx19,
-    avg_pafs HxWx38) float32 at the original image size.  The image-side resize/pad stay on the host like the
-    reference; the network and the per-scale up-sample / crop / resize / average run on the GPU."""
-    import torch
-    normed_img = normalize(img, img_mean, img_scale)
-    height, width, _ = normed_img.shape
-    scales_ratios = [scale * base_height / float(height) for scale in scales]
-    eng = net.engine
-    dev = torch.device("cuda", eng.device_id)
-    avg_heatmaps = torch.zeros((height, width, eng.NH), dtype=torch.float32, device=dev)
-    avg_pafs = torch.zeros((height, width, eng.NP), dtype=torch.float32, device=dev)
-    for ratio in scales_ratios:
-        scaled_img = resize_cubic_float(normed_img, ratio)
-        min_dims = [base_height, max(scaled_img.shape[1], base_height)]
-        padded_img, pad = pad_width(scaled_img, stride, pad_value, min_dims)
-        x = torch.from_numpy(np.ascontiguousarray(padded_img.transpose(2, 0, 1)[None], dtype=np.float32)).to(dev)
-        stages_output = net(x)
-        eng.multiscale_accumulate(avg_heatmaps, stages_output[-2], stride, pad, len(scales_ratios))
-        eng.multiscale_accumulate(avg_pafs, stages_output[-1], stride, pad, len(scales_ratios))
-    return avg_heatmaps.cpu().numpy(), avg_pafs.cpu().numpy()
+    avg_pafs HxWx38) float32 at the original image size.  Everything between the uint8 frame and the averaged maps runs
+    on the GPU: normalize + per-scale cubic resize + pad (lwp_preprocess_scaled_u8), the network, the per-scale
+    up-sample / crop / resize / average (lwp_multiscale_accumulate)."""
+    avg_heatmaps, avg_pafs = infer_batch(net, np.asarray(img)[None], scales, base_height, stride, pad_value, img_mean, img_scale)
+    return avg_heatmaps[0].cpu().numpy(), avg_pafs[0].cpu().numpy()
 
 
-def scaled_inputs(imgs, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
-    """Host side of val.py:84-93 for a batch of same-sized frames: per scale the float32 (N,3,H',W') network input
-    and its pad [top, left, bottom, right]."""
-    height = imgs[0].shape[0]
-    out = []
-    for ratio in [scale * base_height / float(height) for scale in scales]:
-        xs, pad = [], None
-        for img in imgs:
-            scaled_img = resize_cubic_float(normalize(img, img_mean, img_scale), ratio)
-            min_dims = [base_height, max(scaled_img.shape[1], base_height)]
-            padded_img, pad = pad_width(scaled_img, stride, pad_value, min_dims)
-            xs.append(padded_img.transpose(2, 0, 1))
-        out.append((np.ascontiguousarray(np.stack(xs), dtype=np.float32), pad))
-    return out
+def scaled_inputs(net, imgs, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
+    """Image side of val.py:84-93 for a batch of same-sized uint8 frames (numpy or cuda tensor, N x H x W x 3), on the device:
+    per scale the float32 (N,3,H',W') network input (cuda tensor) and its pad [top, left, bottom, right]."""
+    imgs = _as_u8_frames(imgs)
+    height = int(imgs.shape[1])
+    return [net.engine.preprocess_scaled_u8(imgs, scale * base_height / float(height), base_height, stride, pad_value, img_mean, img_scale)
+            for scale in scales]
 
 
 def accumulate_scales(net, inputs, height, width, stride):
@@ -115,11 +74,10 @@ def accumulate_scales(net, inputs, height, width, stride):
 
 
 def infer_batch(net, imgs, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
-    """``infer`` (val.py:81-110) for N same-sized frames at once; returns cuda tensors (N,H,W,19), (N,H,W,38)."""
-    import torch
-    dev = torch.device("cuda", net.engine.device_id)
-    inputs = [(torch.from_numpy(x).to(dev), pad) for x, pad in scaled_inputs(imgs, scales, base_height, stride, pad_value, img_mean, img_scale)]
-    return accumulate_scales(net, inputs, imgs[0].shape[0], imgs[0].shape[1], stride)
+    """``infer`` (val.py:81-110) for N same-sized uint8 frames at once; returns cuda tensors (N,H,W,19), (N,H,W,38)."""
+    imgs = _as_u8_frames(np.stack(list(imgs)) if isinstance(imgs, (list, tuple)) else imgs)
+    inputs = scaled_inputs(net, imgs, scales, base_height, stride, pad_value, img_mean, img_scale)
+    return accumulate_scales(net, inputs, int(imgs.shape[1]), int(imgs.shape[2]), stride)
 
 
 def poses_batch(net, avg_heatmaps, avg_pafs):

@@ -68,8 +68,10 @@ def forward(sd, x, num_refinement_stages=1, taps=None):
         t = a
         for j in range(3):
             t = F.elu(_conv(t, sd, "cpm.trunk.%d.0" % j, 1, 1, 1, t.shape[1]))
+            tap("cpm.trunk.%d.dw" % j, t)
             t = F.elu(_conv(t, sd, "cpm.trunk.%d.2" % j))
             tap("cpm.trunk.%d" % j, t)
+        tap("cpm.sum", a + t)          # x + trunk(x) (with_mobilenet.py:20): the operand of cpm.conv
         feat = _c3(a + t, sd, "cpm.conv.0")
         tap("cpm", feat)
         # initial stage

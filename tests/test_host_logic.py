@@ -199,3 +199,166 @@ def test_world_size_2_broadcast_and_sharding_over_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+def test_bf16_rejects_unsupported_channel_widths():
+    """The bf16 graph exists for num_channels in {64, 128, 256, 512} only: anything else is an argument error
+    at lwp_create, before any device is touched — never f32 kernels on bf16-sized buffers."""
+    L = _lib.lib()
+    for C in (96, 160, 192, 32):
+        h = ctypes.c_void_p()
+        assert L.lwp_create(0, 1, C, 19, 38, _lib.BF16, ctypes.byref(h)) == _lib.LWP_ERR_ARG and not h.value
+        assert b"bf16 path supports" in L.lwp_last_error(None)
+    from lwpose_amd.models.with_mobilenet import PoseEstimationWithMobileNet
+    net = PoseEstimationWithMobileNet(1, num_channels=96, dtype="bf16")
+    with pytest.raises(ValueError):
+        net.cuda()
+
+
+def test_scale_dims_match_the_oracle_pad_width():
+    """lwp_scale_dims (host arithmetic of val.py:89-91) against the oracle's pad_width on the scaled size."""
+    from lwpose_amd.runtime import Engine
+    for H, W, ratio, base, stride in ((368, 656, 0.5, 368, 8), (368, 656, 1.5, 368, 8), (92, 120, 3.0, 184, 8), (75, 333, 2.45, 368, 16),
+                                      (5, 7, 0.5, 368, 8)):
+        dh, dw = int(round(H * ratio)), int(round(W * ratio))
+        _, pad = preproc_ref.pad_width(np.zeros((dh, dw, 3)), stride, (0, 0, 0), [base, max(dw, base)])
+        got = Engine.scale_dims(H, W, ratio, base, stride)
+        assert got[:2] == (dh, dw) and got[4] == pad and got[2:4] == (dh + pad[0] + pad[2], dw + pad[1] + pad[3])
+
+
+def test_checkpoint_round_trip_host_side(tmp_path, capsys):
+    """{'state_dict': ...} written by torch.save is read back with the weights-only loader (nothing in the file is executed)
+    and poured in through load_state: every tensor arrives, a missing key keeps the net's own value and prints the
+    reference's warning (modules/load_state.py:4-15)."""
+    from lwpose_amd.models.with_mobilenet import PoseEstimationWithMobileNet
+    from lwpose_amd.modules.load_state import load_state
+    sd = synth.make_state_dict(1, seed=5)
+    del sd["cpm.conv.0.bias"]
+    path = str(tmp_path / "ck.pth")
+    torch.save({"state_dict": sd, "iter": 370000}, path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    net = PoseEstimationWithMobileNet(1)
+    own = net.state_dict()["cpm.conv.0.bias"].clone()
+    load_state(net, ck)
+    assert capsys.readouterr().out == "[WARNING] Not found pre-trained parameters for cpm.conv.0.bias\n"
+    after = net.state_dict()
+    assert torch.equal(after["cpm.conv.0.bias"], own)
+    assert all(torch.equal(after[k], v) for k, v in sd.items())
+
+
+# ------------------------------------------------------------------------------------------ tail of the path: oracle pins + product
+def test_tail_oracle_hand_cases():
+    """oracle/tail_ref.py against values derived by hand from demo.py:101-114 and pose.py:21-45 (cv2 is absent, so the
+    reference's own functions cannot be imported: 'parity unpinned' beyond these cases)."""
+    from oracle import tail_ref
+    allk = np.array([[100.0, 40.0, 0.9, 0], [37.0, 81.0, 0.8, 1], [2.0, 1.0, 0.7, 2]])
+    ent = -np.ones((2, 20)); ent[0, 0] = 0; ent[0, 1] = 1; ent[0, 18] = 3.25; ent[0, 19] = 2
+    ent[1, 5] = 2; ent[1, 18] = 1.5; ent[1, 19] = 1
+    poses = tail_ref.poses_from_entries(ent, allk.copy(), 0.8, [4, 6, 4, 6], 8, 4)
+    # x = (x * 8 / 4 - pad[1]) / scale ; y = (y * 8 / 4 - pad[0]) / scale ; int() truncates toward zero
+    assert poses[0].keypoints[0].tolist() == [int((200 - 6) / 0.8), int((80 - 4) / 0.8)] == [242, 95]
+    assert poses[0].keypoints[1].tolist() == [int((74 - 6) / 0.8), int((162 - 4) / 0.8)] == [85, 197]
+    assert poses[1].keypoints[5].tolist() == [int((4 - 6) / 0.8), int((2 - 4) / 0.8)] == [-2, -2]       # truncation, not floor
+    assert (poses[0].keypoints[2:] == -1).all() and poses[0].confidence == 3.25
+    assert poses[0].bbox == (85, 95, 242 - 85 + 1, 197 - 95 + 1) and poses[1].bbox == (-2, -2, 1, 1)
+    tail_ref.RefPose.last_id = -1
+    poses[0].update_id(); poses[1].update_id(); poses[0].update_id(7)
+    assert (poses[0].id, poses[1].id, tail_ref.RefPose.last_id) == (7, 1, 1)
+    f = tail_ref.RefOneEuro(freq=15, beta=0.1)
+    ref = json.load(open(os.path.join(GOLDEN, "one_euro.json")))
+    assert [float(f(x)) for x in ref["x"]] == ref["y"]                   # the filter restatement IS pinned to the reference
+
+
+def _people_sequence(seed, n_frames=5, n_people=4, drop=0.15):
+    """Seeded walk of ``n_people`` skeletons: per frame a list of ((18,2) int32 key-points, confidence)."""
+    rng = np.random.RandomState(seed)
+    base = rng.randint(40, 400, size=(n_people, 1, 2)) + rng.randint(-30, 31, size=(n_people, 18, 2))
+    vel = rng.randint(-6, 7, size=(n_people, 1, 2))
+    frames = []
+    for t in range(n_frames):
+        cur = []
+        order = rng.permutation(n_people)
+        for p in order[: n_people - (1 if t == 2 else 0)]:          # one person vanishes in frame 2 and comes back
+            kp = (base[p] + vel[p] * t + rng.randint(-2, 3, size=(18, 2))).astype(np.int32)
+            kp[rng.rand(18) < drop] = -1
+            cur.append((kp, float(rng.rand() * 10)))
+        if t == 3:
+            cur.append((rng.randint(500, 600, size=(18, 2)).astype(np.int32), 0.5))   # a newcomer far away
+        frames.append(cur)
+    return frames
+
+
+@pytest.mark.parametrize("smooth", [False, True])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_track_poses_matches_oracle_on_sequences(seed, smooth):
+    """modules.pose.track_poses / Pose vs the oracle restatement of pose.py:65-118 on seeded 5-frame, 4-person sequences:
+    ids, greedy mask order (most confident first, first maximum wins), >= threshold rule, filter hand-over only where the
+    previous pose has the key-point, smoothed key-points and refreshed boxes."""
+    from lwpose_amd.modules.pose import Pose, track_poses
+    from oracle import tail_ref
+    Pose.last_id = -1
+    tail_ref.RefPose.last_id = -1
+    prev_a, prev_b = [], []
+    for cur in _people_sequence(seed):
+        a = [Pose(kp.copy(), c) for kp, c in cur]
+        b = [tail_ref.RefPose(kp.copy(), c) for kp, c in cur]
+        track_poses(prev_a, a, smooth=smooth)
+        tail_ref.track_poses(prev_b, b, smooth=smooth)
+        assert [p.id for p in a] == [p.id for p in b]
+        for p, q in zip(a, b):
+            assert np.array_equal(p.keypoints, q.keypoints) and tuple(p.bbox) == tuple(q.bbox)
+            if smooth:
+                for k in range(18):
+                    assert (p.filters[k][0].x_previous, p.filters[k][0].dx) == (q.filters[k][0].raw_prev, q.filters[k][0].dx)
+        prev_a, prev_b = a, b
+    assert Pose.last_id == tail_ref.RefPose.last_id >= 4
+    ids = [p.id for p in prev_a]
+    assert len(set(ids)) == len(ids)
+
+
+def test_track_poses_corner_cases_match_oracle():
+    """threshold <= 0 with nothing similar (NumPy's mask[None] = 0 clears every flag), previous poses without ids, and
+    get_similarity on identical / disjoint poses."""
+    from lwpose_amd.modules.pose import Pose, get_similarity, track_poses
+    from oracle import tail_ref
+    fr = _people_sequence(9, n_frames=2)
+    for threshold, give_ids in ((0, True), (3, False), (19, True), (1, True)):
+        Pose.last_id = tail_ref.RefPose.last_id = -1
+        pa = [Pose(kp.copy(), c) for kp, c in fr[0]]
+        pb = [tail_ref.RefPose(kp.copy(), c) for kp, c in fr[0]]
+        if give_ids:
+            track_poses([], pa); tail_ref.track_poses([], pb)
+        far = [(kp + 5000, c) for kp, c in fr[1][:2]] + fr[1][2:]          # two poses similar to nobody
+        ca = [Pose(kp.copy(), c) for kp, c in far]
+        cb = [tail_ref.RefPose(kp.copy(), c) for kp, c in far]
+        track_poses(pa, ca, threshold=threshold, smooth=True)
+        tail_ref.track_poses(pb, cb, threshold=threshold, smooth=True)
+        assert [p.id for p in ca] == [p.id for p in cb], (threshold, give_ids)
+        assert all(np.array_equal(p.keypoints, q.keypoints) for p, q in zip(ca, cb))
+    a, b = Pose(fr[0][0][0].copy(), 1.0), tail_ref.RefPose(fr[0][0][0].copy(), 1.0)
+    assert get_similarity(a, a) == tail_ref.get_similarity(b, b) == int((fr[0][0][0][:, 0] != -1).sum())
+
+
+def test_bench_multi_rank_protocol_over_gloo(tmp_path):
+    """The REAL bench.py N > 1 code path (init_process_group, one weight broadcast, per-rank shards, barrier-bracketed
+    timed blocks of exactly K steps, MAX over ranks, one JSON line on rank 0) with world_size 2 over gloo; the engines are
+    sleeping stand-ins (tests/stub_engine.py), rank 1 twice as slow as rank 0."""
+    port = 31500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--batch", "3",
+           "--min-time", "0.1", "--preroll", "0.01"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", LWP_BENCH_ENGINE_FACTORY="tests.stub_engine:make")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 6 and out["unit"] == "frames/s" and out["higher_is_better"] is True
+    assert "rehearsal" in out and out["roofline"] is None and out["cpu_baseline"] is None
+    from tests.stub_engine import STEP_SECONDS
+    # the slow rank (2 x STEP_SECONDS per step) sets the time: max over ranks, not rank 0's own clock
+    assert out["ms_per_step"] >= 2 * STEP_SECONDS * 1e3 * 0.98
+    assert abs(out["value"] - 6 * 6 / (out["ms_per_step"] * 6 / 1e3)) < 1e-6 * out["value"]
+    assert out["timed_blocks"] == len(out["block_values"]) >= 2
+    assert out["block_spread"]["min"] <= out["value"] <= out["block_spread"]["max"]
