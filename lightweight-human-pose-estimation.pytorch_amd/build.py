@@ -17,7 +17,10 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-u
 # the post-processing must reproduce NumPy's separately-rounded float32/float64 arithmetic bit for bit:
 # no FMA contraction anywhere in that translation unit (the in-source pragma alone is not honoured for
 # packed-math fusion by hipcc 7.2)
-EXTRA = {"post_kernels.hip": ["-ffp-contract=off"] + (["-DLWP_ASM_STAMPS"] if os.environ.get("LWP_ASM_STAMPS") else [])}
+EXTRA = {"post_kernels.hip": ["-ffp-contract=off"] + (["-DLWP_ASM_STAMPS"] if os.environ.get("LWP_ASM_STAMPS") else []),
+         # LWP_ABLATION=1 at build time adds the ablation instantiations of the hot kernels (tools/ only; never shipped by default)
+         "net_kernels_bf16.hip": (["-DLWP_ABLATION"] if os.environ.get("LWP_ABLATION") else []),
+         "net_kernels.hip": (["-DLWP_ABLATION"] if os.environ.get("LWP_ABLATION") else [])}
 
 
 def _stale():

@@ -417,8 +417,405 @@ static hipError_t launch_gemm_bf16_t(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------- implicit GEMM, activation window resident
+// Dense 3x3 convs with 128 input channels at large M (batch 32: M = 120704 pixels, N = 128, K = 9 x 128).
+// The nine A tiles of a 3x3 conv are ONE pixel window at nine offsets: with pixels flat over (n, y, x) the window of the tile
+// [m0, m0 + BM) is the contiguous run [m0 - dil*(W+1), m0 + BM + dil*(W+1)) of NHWC rows.  The workgroup keeps ONE 64-channel
+// block of that run in LDS (rows of 64 bf16 + 16 B of padding: conflict-free ds_read_b128), walks the nine taps over it, then
+// overwrites it with the second block — which has been waiting in registers since the start of the tile — and walks the taps
+// again.  The K loop therefore moves only the weights (16 KB per 64-deep step through a double-buffered LDS tile, one barrier
+// per step, BD steps in flight in a register ring); a tap outside the image reads a zero row (select on the lane's LDS address).
+// With 128-row tiles the whole working set is 79 KB, so TWO workgroups share a CU and cover each other's staging, barrier
+// and epilogue phases; dilation-2 layers need 256-row tiles (1 workgroup per CU).
+// Ablation of the first version (256 rows, full 128-channel window, 1 workgroup per CU, us per launch at batch 32, total 68.5):
+// launch floor 3-5.7, scattered 8-byte epilogue stores 18.6, window staging 7.2, LDS fragment reads alone 23, MFMA bound 16.2;
+// after fragment double-buffering, exact vmcnt counting (no data-dependent branch in the loop) and the LDS-transposed
+// epilogue: 44.1 = floor 3.0 + staging 3.3 + K loop 29 + epilogue 11 (all CUs write at once: HBM-write bound, nothing overlaps).
+// Epilogue: bias + activation in registers, f32 tile through the (now free) LDS, then 16-byte fully coalesced stores of whole
+// 256-byte pixel rows (residual added from equally coalesced loads, rounded to bf16 once).
+// DBG (compile time, 0 in production; LWP_GEMMH_DEBUG selects an ablation build of the 256-row configuration):
+// 1 no epilogue, 2 no MFMA, 4 no window staging, 8 no weight stream, 16 no K loop
+template <int BM, int WM, int WN, int KSZ, int BD, int WCH, int DBG = 0>     // WCH: 16-byte window chunks per thread and channel block
+__global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BN = 128, CIN = 128;
+    constexpr int RM = BM / WM / 32, RN = BN / WN / 32;
+    constexpr int B_PER = BN * 8 / NT;                 // 16-byte chunks of the weight tile per thread
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0 && (BN * 8) % NT == 0, "tile / wave mismatch");
+    constexpr int taps = KSZ * KSZ;
+    constexpr int CS = HBK + 8;                        // window row stride (elements): 144 B
+    constexpr int kblocks = CIN / HBK;                 // 2
+    constexpr int nsteps = kblocks * taps;
+    static_assert(kblocks == 2, "one block resident, one in registers");
+    extern __shared__ __attribute__((aligned(16))) unsigned char arm_raw[];
+    const int halo = KSZ == 3 ? p.dil * (p.W + 1) : 0;
+    const int R = BM + 2 * halo;                       // window rows
+    __bf16* Aw = (__bf16*)arm_raw;                     // [R + 1][CS]  (last row: zeros)
+    __bf16* zrow = Aw + (size_t)R * CS;
+    __bf16* Bs = zrow + CS;                            // [2][BN][HLD]
+    const __bf16* in = (const __bf16*)p.in;
+    const __bf16* wgt = (const __bf16*)p.w;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int M = p.N * p.H * p.W;                     // host guarantees < 2^31
+    const int ntn = p.cout_pad / BN;
+    const int ntiles = ((M + BM - 1) / BM) * ntn;
+    // persistent workgroups: block b walks the tiles remap(b), remap(b) + G, ...  (XCD-aware order of the first index: the
+    // blocks of one XCD take neighbouring tiles, whose windows overlap by the halo)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    }
+
+    // ---- weight tile staging: BD steps in flight in a statically indexed register ring, double-buffered in LDS
+    int b_off[B_PER], b_lds[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int ch = tid + i * NT;
+        const int row = ch >> 3, col = (ch & 7) * 8;
+        b_off[i] = row * CIN + col;
+        b_lds[i] = row * HLD + col;
+    }
+    bf16x8 b_reg[BD][B_PER];
+    int n0 = 0;                                        // first output channel of the tile whose weights are being streamed
+    auto load_b = [&](int step, bf16x8* dst) {
+        const int kb = step / taps, tap = step - kb * taps;
+        const __bf16* wt = wgt + ((int64_t)tap * p.cout_pad + n0) * CIN + kb * HBK;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) dst[i] = *(const bf16x8*)(wt + b_off[i]);
+    };
+    auto store_b = [&](int buf, const bf16x8* src) {
+        __bf16* b = Bs + buf * BN * HLD;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) *(bf16x8*)(b + b_lds[i]) = src[i];
+    };
+
+    // ---- pixel window: row r <-> flat pixel m0 - halo + r.  Channel block 0 goes to LDS at the start of the tile; block 1 is
+    // loaded behind it into registers (WCH 16-byte chunks per thread) and replaces block 0 in LDS after the ninth tap.
+    const int wtotal = R * 8;                                    // chunks of one 64-channel block (<= WCH * NT: host check)
+    bf16x8 wreg[WCH];
+    auto win_load = [&](int m0_, int kb) {
+#pragma unroll
+        for (int u = 0; u < WCH; ++u) {
+            const int ch = tid + u * NT;
+            const int row = ch >> 3, col = (ch & 7) * 8 + kb * HBK;
+            const int g = m0_ - halo + row;
+            const __bf16* src = (ch < wtotal && g >= 0 && g < M) ? in + (int64_t)g * p.in_ld + col : (const __bf16*)p.zeros;
+            wreg[u] = *(const bf16x8*)src;
+        }
+    };
+    auto win_write = [&]() {
+#pragma unroll
+        for (int u = 0; u < WCH; ++u) {
+            const int ch = tid + u * NT;
+            if (ch < wtotal) *(bf16x8*)(Aw + (size_t)(ch >> 3) * CS + (ch & 7) * 8) = wreg[u];
+        }
+    };
+    // everything of the NEXT tile that can be requested early: its weights (ring) and block 0 of its window (registers)
+    auto prefetch_tile = [&](int tile) {
+        n0 = (tile % ntn) * BN;
+        if (!(DBG & 8)) {
+#pragma unroll
+            for (int d = 0; d < BD; ++d) load_b(d, b_reg[d]);
+        }
+        if (!(DBG & 4)) win_load((tile / ntn) * BM, 0);
+    };
+
+    const int zoff = R * CS + 8 * h;                   // the zero row, as an offset from Aw
+    const int b_lane = (wn * RN * 32 + i32) * HLD + 8 * h;
+    using std::integral_constant;
+    typedef integral_constant<bool, false> no_t;
+    typedef integral_constant<bool, true> yes_t;
+    static_assert(taps % BD == 0, "the restage step must sit at a fixed ring position");
+
+    int tile = bid;
+    if (tile < ntiles) prefetch_tile(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = (tile / ntn) * BM;
+        const int n0_cur = (tile % ntn) * BN;
+        // ---- start of the tile: block 0 of the window lands in LDS (its loads were issued a tile ago), block 1 is requested
+        if (!(DBG & 4)) {
+            win_write();
+            win_load(m0, 1);                               // in flight during the first nine steps
+        }
+        for (int c = tid * 8; c < CS; c += NT * 8) *(bf16x8*)(zrow + c) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        store_b(0, b_reg[0]);
+
+        // the lane's pixels: window row of the tap (0, 0) and the taps that fall inside the image
+        int a_row[RM];
+        unsigned valid[RM];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            const int lp = (wm * RM + i) * 32 + i32;       // pixel within the tile
+            const int m = m0 + lp;
+            const bool row_ok = m < M;
+            const int mm = row_ok ? m : 0;
+            const int qy = mm / p.W;
+            const int x = mm - qy * p.W, y = qy % p.H;
+            unsigned v = 0;
+#pragma unroll
+            for (int t = 0; t < taps; ++t) {
+                const int yy = y + (KSZ == 3 ? (t / 3 - 1) * p.dil : 0), xx = x + (KSZ == 3 ? (t % 3 - 1) * p.dil : 0);
+                if (row_ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v |= 1u << t;
+            }
+            valid[i] = v;
+            a_row[i] = lp * CS + 8 * h;                    // element offset; + tap offset (ty*dil*W + tx*dil) * CS
+        }
+        auto a_off = [&](int step, int i) -> int {
+            const int tap = step < taps ? step : step - taps;
+            const int toff = KSZ == 3 ? ((tap / 3) * p.dil * p.W + (tap % 3) * p.dil) * CS : 0;
+            return ((valid[i] >> tap) & 1u) ? a_row[i] + toff : zoff;
+        };
+
+        f32x16 acc[RM][RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        // fragment registers, double-buffered over the 16-deep sub-steps
+        bf16x8 xa[2][RM], wb[2][RN];
+        int ao[RM];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) ao[i] = a_off(0, i);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RM; ++i) xa[0][i] = *(const bf16x8*)(Aw + ao[i]);
+
+        // one K step; JB (compile time) = position in the register ring, RESTAGE = the last step on channel block 0.
+        // No data-dependent branch inside: look-ahead indices are clamped (the last steps reload / restore harmlessly), so the
+        // compiler's vmcnt counting stays exact and BD - 1 weight steps really stay in flight across the barrier.
+        auto do_step = [&](int step, auto JB_, auto RESTAGE_) {
+            constexpr int jb = decltype(JB_)::value;
+            constexpr bool restage = decltype(RESTAGE_)::value;
+            const int buf = step & 1;
+            if (!(DBG & 8)) load_b(step + BD < nsteps ? step + BD : nsteps - 1, b_reg[jb]);      // set jb held step `step`, which is in LDS already
+            const __bf16* b = Bs + buf * BN * HLD + b_lane;
+#pragma unroll
+            for (int j = 0; j < RN; ++j) wb[0][j] = *(const bf16x8*)(b + j * 32 * HLD);
+            int an[RM];                                          // next step's activation offsets
+#pragma unroll
+            for (int i = 0; i < RM; ++i) an[i] = a_off(step + 1 < nsteps ? step + 1 : step, i);
+#pragma unroll
+            for (int s = 0; s < HBK / 16; ++s) {
+                const int c = s & 1, n = c ^ 1;
+                if (s + 1 < HBK / 16) {
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) xa[n][i] = *(const bf16x8*)(Aw + ao[i] + 16 * (s + 1));
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) wb[n][j] = *(const bf16x8*)(b + j * 32 * HLD + 16 * (s + 1));
+                } else if (!restage) {
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) xa[n][i] = *(const bf16x8*)(Aw + an[i]);      // next step, sub-step 0: before the barrier
+                }
+                if (DBG & 2) {
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) asm volatile("" ::"v"(xa[c][i]));
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) asm volatile("" ::"v"(wb[c][j]));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < RM; ++i)
+#pragma unroll
+                        for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[c][j], xa[c][i], acc[i][j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RM; ++i) ao[i] = an[i];
+            if (!(DBG & 8)) store_b(buf ^ 1, b_reg[(jb + 1) % BD]);
+            __syncthreads();
+            if (restage) {                                       // every wave is past its last read of block 0: block 1 takes its place
+                if (!(DBG & 4)) win_write();
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < RM; ++i) xa[0][i] = *(const bf16x8*)(Aw + ao[i]);
+            }
+        };
+        if (!(DBG & 16)) {
+            for (int kb = 0; kb < kblocks; ++kb) {
+                const int s00 = kb * taps;
+                for (int s0 = s00; s0 < s00 + taps - BD; s0 += BD) {
+                    do_step(s0, integral_constant<int, 0>{}, no_t{});
+                    if (BD > 1) do_step(s0 + 1, integral_constant<int, 1 % BD>{}, no_t{});
+                    if (BD > 2) do_step(s0 + 2, integral_constant<int, 2 % BD>{}, no_t{});
+                }
+                const int sl = s00 + taps - BD;
+                if (kb == 0) {
+                    if (BD == 1) do_step(sl, integral_constant<int, 0>{}, yes_t{});
+                    if (BD == 3) { do_step(sl, integral_constant<int, 0>{}, no_t{}); do_step(sl + 1, integral_constant<int, 1 % BD>{}, no_t{}); do_step(sl + 2, integral_constant<int, 2 % BD>{}, yes_t{}); }
+                } else {
+                    do_step(sl, integral_constant<int, 0>{}, no_t{});
+                    if (BD > 1) do_step(sl + 1, integral_constant<int, 1 % BD>{}, no_t{});
+                    if (BD > 2) do_step(sl + 2, integral_constant<int, 2 % BD>{}, no_t{});
+                }
+            }
+        }
+
+        // ---- the next tile's weights and first window block are requested now: they travel while this tile's epilogue runs
+        if (tile + (int)gridDim.x < ntiles) prefetch_tile(tile + gridDim.x);
+
+        // ---- epilogue.  D row = channel (e&3) + 8*(e>>2) + 4*h of the 32-channel tile, col = pixel i32: bias + activation in
+        // registers, f32 tile [BM][132] through LDS (all waves are past the last barrier: window and weight tiles are dead)
+        if (DBG & 1) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+            if (sum == 12345.678f) ((__bf16*)p.out)[0] = (__bf16)sum;
+            continue;
+        }
+        constexpr int OS = BN + 4;                          // 528-byte rows: conflict-free ds_write_b128 for the accumulator layout
+        float* Ot = (float*)arm_raw;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            const int lp = (wm * RM + i) * 32 + i32;
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = (wn * RN + j) * 32 + 8 * g + 4 * h;
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    v += *(const f32x4*)(p.bias + n0_cur + nl);           // bias is padded to cout_pad
+                    v.x = act_f(v.x, p.act); v.y = act_f(v.y, p.act); v.z = act_f(v.z, p.act); v.w = act_f(v.w, p.act);
+                    *(f32x4*)(Ot + lp * OS + nl) = v;
+                }
+            }
+        }
+        __syncthreads();
+        __bf16* out = (__bf16*)p.out;
+        const __bf16* res = (const __bf16*)p.res;
+        constexpr int OCH = BM * (BN / 8) / NT;             // 16-byte output chunks per thread
+        constexpr int OG = OCH >= 4 ? 4 : OCH;              // chunks per pass (bounds the residual registers)
+#pragma unroll
+        for (int u0 = 0; u0 < OCH; u0 += OG) {
+            bf16x8 rv[OG];
+            if (res) {
+#pragma unroll
+                for (int u = 0; u < OG; ++u) {
+                    const int ch = tid + (u0 + u) * NT;
+                    const int row = ch >> 4, col = (ch & 15) * 8;
+                    const int m = m0 + row;
+                    rv[u] = (m < M && n0_cur + col < p.cout) ? *(const bf16x8*)(res + (int64_t)m * p.res_ld + n0_cur + col) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < OG; ++u) {
+                const int ch = tid + (u0 + u) * NT;
+                const int row = ch >> 4, col = (ch & 15) * 8;
+                const int m = m0 + row;
+                if (m >= M || n0_cur + col >= p.cout) continue;     // cout is a multiple of 8 here (host check)
+                const f32x4 v0 = *(const f32x4*)(Ot + row * OS + col), v1 = *(const f32x4*)(Ot + row * OS + col + 4);
+                float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)(res ? f[e] + (float)rv[u][e] : f[e]);
+                *(bf16x8*)(out + (int64_t)m * p.out_ld + n0_cur + col) = o;
+            }
+        }
+        __syncthreads();                                    // the f32 tile has been read: the next tile's window may overwrite it
+    }
+}
+
+static int device_cu_count() {
+    static int cus[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
+static size_t gemm_bf16_ar_lds(const GemmParams& p, int BM) {
+    const int halo = p.ks == 3 ? p.dil * (p.W + 1) : 0;
+    const size_t loop = ((size_t)(BM + 2 * halo + 1) * (HBK + 8) + (size_t)2 * 128 * HLD) * 2;
+    const size_t epi = (size_t)BM * (128 + 4) * 4;
+    return loop > epi ? loop : epi;
+}
+
+template <int BM, int WM, int WN, int KSZ, int BD, int WCH, int DBG = 0>
+static hipError_t launch_gemm_bf16_ar_w(const GemmParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    const int64_t tiles = ((M + BM - 1) / BM) * (p.cout_pad / 128);
+    static LdsAttrOnce attr;
+    hipError_t e = attr.ensure((const void*)gemm_bf16_ar_kernel<BM, WM, WN, KSZ, BD, WCH, DBG>, 160 * 1024);
+    if (e != hipSuccess) return e;
+    // persistent workgroups: one per CU (or two when two fit), each walking tiles b, b + G, ...
+    static const char* penv = getenv("LWP_GEMMH_PERSIST");   // "0": one workgroup per tile (A/B)
+    const size_t lds = gemm_bf16_ar_lds(p, BM);
+    int64_t grid = tiles;
+    if (!(penv && penv[0] == '0')) {
+        const int64_t slots = (int64_t)device_cu_count() * (lds <= 80 * 1024 ? 2 : 1);
+        if (grid > slots) grid = slots;
+    }
+    hipLaunchKernelGGL((gemm_bf16_ar_kernel<BM, WM, WN, KSZ, BD, WCH, DBG>), dim3((unsigned)grid), dim3(WM * WN * 64), lds, s, p);
+    return hipGetLastError();
+}
+template <int BM, int WM, int WN, int KSZ, int BD, int DBG = 0>
+static hipError_t launch_gemm_bf16_ar_t(const GemmParams& p, hipStream_t s) {
+    // window chunks per thread: two register budgets (the window block waits in registers for nine steps)
+    constexpr int NT = WM * WN * 64;
+    const int halo = p.ks == 3 ? p.dil * (p.W + 1) : 0;
+    const int need = ((BM + 2 * halo) * 8 + NT - 1) / NT;
+    constexpr int W_SMALL = ((BM + 2 * 96) * 8 + NT - 1) / NT, W_LARGE = ((BM + 2 * 180) * 8 + NT - 1) / NT;
+    if (need <= W_SMALL) return launch_gemm_bf16_ar_w<BM, WM, WN, KSZ, BD, W_SMALL, DBG>(p, s);
+    if (need <= W_LARGE) return launch_gemm_bf16_ar_w<BM, WM, WN, KSZ, BD, W_LARGE, DBG>(p, s);
+    return hipErrorInvalidValue;
+}
+
+// picks the window-resident kernel when the tile's window fits the LDS; *used = false: caller falls back
+static hipError_t try_gemm_bf16_ar(const GemmParams& p, hipStream_t s, bool* used) {
+    *used = false;
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    static const char* env = getenv("LWP_GEMMH_AR");         // "0": off; "BM,WM,WN,BD": force a configuration (experiments)
+    if (env && env[0] == '0' && env[1] == 0) return hipSuccess;
+    if (p.ks != 3 || p.cout_pad % 128 != 0 || p.cin_pad != 128 || (p.cout & 7) || p.out_nchw || p.out_nchw2 || M >= (1ll << 31) - 512) return hipSuccess;
+    if ((p.out_ld & 7) || (((uintptr_t)p.out) & 15) || (p.in_ld & 7) || (((uintptr_t)p.in) & 15)) return hipSuccess;
+    if (p.res && ((p.res_ld & 7) || (((uintptr_t)p.res) & 15))) return hipSuccess;
+    if (p.dil * (p.W + 1) > 180) return hipSuccess;           // the kernel's register budget for the window block held in registers
+    if (M < 128 * 256) return hipSuccess;                     // small problems: the shared-tile kernel's 64 x 64 tiles fill the chip better
+    int bm = 0, wm = 0, wn = 0, bd = 0;
+    if (!(env && sscanf(env, "%d,%d,%d,%d", &bm, &wm, &wn, &bd) == 4)) {
+        // (128-row tiles, two workgroups per CU, measured slower at batch 32: 64.9 us against 44.3 for 256 rows, dilation 1)
+        if (gemm_bf16_ar_lds(p, 256) <= 160 * 1024) { bm = 256; wm = 4; wn = 2; bd = 3; }
+        else if (gemm_bf16_ar_lds(p, 128) <= 160 * 1024) { bm = 128; wm = 2; wn = 2; bd = 3; }
+        else return hipSuccess;
+    }
+    if (gemm_bf16_ar_lds(p, bm) > 160 * 1024) return hipSuccess;
+    *used = true;
+#ifdef LWP_ABLATION
+    static const char* dbg = getenv("LWP_GEMMH_DEBUG");
+    const int d = dbg ? atoi(dbg) : 0;
+#define GAR_DBG(D_) if (bm == 256 && wm == 4 && wn == 2 && d == D_) return launch_gemm_bf16_ar_t<256, 4, 2, 3, 3, D_>(p, s); \
+                    if (bm == 128 && wm == 2 && wn == 2 && d == D_) return launch_gemm_bf16_ar_t<128, 2, 2, 3, 3, D_>(p, s);
+    GAR_DBG(1) GAR_DBG(2) GAR_DBG(4) GAR_DBG(8) GAR_DBG(16) GAR_DBG(17) GAR_DBG(21) GAR_DBG(10) GAR_DBG(14) GAR_DBG(15)
+#undef GAR_DBG
+#endif
+#define GAR_CASE(BM_, WM_, WN_, BD_) if (bm == BM_ && wm == WM_ && wn == WN_ && bd == BD_) return launch_gemm_bf16_ar_t<BM_, WM_, WN_, 3, BD_>(p, s);
+    GAR_CASE(256, 4, 2, 3) GAR_CASE(128, 2, 2, 3) GAR_CASE(128, 2, 2, 1) GAR_CASE(128, 4, 2, 3) GAR_CASE(256, 4, 2, 1)
+#undef GAR_CASE
+    *used = false;
+    return hipSuccess;
+}
+
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.H * p.W;
+    {
+        bool used = false;
+        hipError_t e = try_gemm_bf16_ar(p, s, &used);
+        if (e != hipSuccess || used) return e;
+    }
     // experiments: LWP_GEMMH = "BM,BN,RM,RN"
     static const char* env = getenv("LWP_GEMMH");
     int bm = 0, bn = 0, rm = 0, rn = 0;
