@@ -378,7 +378,7 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
     level_dims(H, W, g.bufs[l.dst.buf].level, &dh, &dw);
     float* dst = buf_at(h, l.dst);
     if (l.kind == L_STEM) {
-        StemParams p{d_in, wts, bias, dst, N, H, W, dh, dw};
+        StemParams p{d_in, wts, bias, dst, N, H, W, dh, dw, h->d_zeros};
         LAUNCH(h, KC_STEM, h16 ? launch_stem_bf16(p, h->stream) : launch_stem(p, h->stream));
     } else if (l.kind == L_DWPW) {
         int sh, sw;

@@ -82,12 +82,13 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names,
                          const std::vector<HostTensor>& tensors, std::vector<float>& blob);
 
 // ------------------------------------------------------------------ kernel launch parameters
-struct StemParams {
-    const float* in;     // N x 3 x H x W
-    const float* w;      // [27][32]  (ky, kx, ci) major, oc minor
-    const float* bias;   // [32]
-    float* out;          // N x Ho x Wo x 32
+struct StemParams {       // (__restrict__: the weights stay scalar loads although the kernel loops over tiles and stores in between)
+    const float* __restrict__ in;     // N x 3 x H x W
+    const float* __restrict__ w;      // [27][32]  (ky, kx, ci) major, oc minor
+    const float* __restrict__ bias;   // [32]
+    float* __restrict__ out;          // N x Ho x Wo x 32
     int N, H, W, Ho, Wo;
+    const float* zeros = nullptr;   // >= 16 bytes of zeros (source of out-of-image quads)
 };
 struct DwParams {
     const float* in; int in_ld;      // NHWC, row stride in_ld

@@ -33,59 +33,99 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // arriving through scalar loads (uniform addresses); results are transposed through LDS so the write-out is
 // 16 bytes per lane on consecutive addresses (4 KiB contiguous per tile row).
 constexpr int ST_TX = 32;
-template <bool BF16, int ST_TY>
+// DBG (LWP_ABLATION builds): 1 no input staging, 2 no FMAs, 4 no write-out.
+// Ablation of the first version at batch 32 fp32 (158 us): input staging alone 59 us (one 4-byte load per element with two
+// integer divisions), the 864 FMAs per pixel 50 us, the write-out 29 us, launch floor 7.5 — and hardly any overlap between
+// them (3 workgroups per CU).  Now: the region is staged with ALIGNED 16-byte row loads (18 per row and channel: columns
+// 2*x0 - 4 .. 2*x0 + 67; image edges fall on multiples of 4, so a quad is either inside or zero) when W % 4 == 0, and the
+// output staging tile re-uses the input tile's LDS (36.9 KB per workgroup: 4 workgroups per CU).
+// PY = vertically adjacent output pixels per thread (tile = ST_TY*PY rows x 32 columns).  The 27 x 32 weights reach the FMAs
+// as scalar operands: every (tap, channel) needs two s_load_dwordx16 whose latency the compiler does not hide (it waits
+// lgkmcnt(0) in front of each group of 32 v_fmac), so with PY = 2 each scalar load feeds 64 FMAs instead of 32.
+// PY = vertically adjacent output pixels per thread (tile = ST_TY*PY rows x 32 columns); every (tap, channel) needs two
+// s_load_dwordx16 of weights, which PY = 2 amortises over 64 FMAs — measured equal to PY = 1 at batch 32, kept for experiments.
+// (A persistent form that requests the next tile's quads before the FMAs was measured and dropped: 143 us against 104 —
+// the parked quads cost a wave of occupancy and, inside a tile loop, the weights are only scalar-loaded when read through
+// the constant address space.)
+template <bool BF16, int ST_TY, int PY = 1, int DBG = 0>
 __global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
     constexpr int NT = ST_TY * ST_TX;
-    constexpr int IR = 2 * ST_TY + 1, IC = 2 * ST_TX + 1;          // 17 x 65 input region per channel
-    constexpr int OLD = BF16 ? 20 : 36;                            // staged row stride in dwords (80 B / 144 B)
-    __shared__ float s_in[3][IR][IC + 1];
-    __shared__ __attribute__((aligned(16))) float s_out[NT * OLD];
+    constexpr int TROWS = ST_TY * PY;                              // output rows per tile
+    constexpr int IR = 2 * TROWS + 1;                              // input rows per channel
+    constexpr int IQ = 18, ICP = IQ * 4;                           // 18 aligned quads = 72 columns: LDS column j <-> x = 2*x0 - 4 + j
+    constexpr int OLD = BF16 ? 20 : 36;                            // staged output row stride in dwords (80 B / 144 B)
+    constexpr int IN_FLOATS = 3 * IR * ICP, OUT_FLOATS = NT * OLD;
+    __shared__ __attribute__((aligned(16))) float smem[IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS];
+    float* s_in = smem;                                            // [3][IR][ICP]
+    float* s_out = smem;                                           // [NT][OLD]  (after the compute phase, one pixel of every thread at a time)
     const int tid = threadIdx.x;
     const int tiles_x = (p.Wo + ST_TX - 1) / ST_TX;
-    const int x0 = (blockIdx.x % tiles_x) * ST_TX, y0 = (blockIdx.x / tiles_x) * ST_TY;
+    const int x0 = (blockIdx.x % tiles_x) * ST_TX, y0 = (blockIdx.x / tiles_x) * TROWS;
     const int n = blockIdx.y;
     const float* in = p.in + (int64_t)n * 3 * p.H * p.W;
-    for (int i = tid; i < 3 * IR * IC; i += NT) {
-        const int col = i % IC, r = (i / IC) % IR, c = i / (IC * IR);
-        const int yi = 2 * y0 - 1 + r, xi = 2 * x0 - 1 + col;
-        float v = 0.f;
-        if (yi >= 0 && yi < p.H && xi >= 0 && xi < p.W) v = in[((int64_t)c * p.H + yi) * p.W + xi];
-        s_in[c][r][col] = v;
+    if (!(DBG & 1)) {
+        if ((p.W & 3) == 0 && (((uintptr_t)p.in) & 15) == 0) {
+            for (int i = tid; i < 3 * IR * IQ; i += NT) {
+                const int qd = i % IQ, r = (i / IQ) % IR, c = i / (IQ * IR);
+                const int yi = 2 * y0 - 1 + r, xi = 2 * x0 - 4 + 4 * qd;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (yi >= 0 && yi < p.H && xi >= 0 && xi < p.W) v = *(const f32x4*)(in + ((int64_t)c * p.H + yi) * p.W + xi);
+                *(f32x4*)(s_in + (c * IR + r) * ICP + 4 * qd) = v;
+            }
+        } else {
+            for (int i = tid; i < 3 * IR * ICP; i += NT) {
+                const int col = i % ICP, r = (i / ICP) % IR, c = i / (ICP * IR);
+                const int yi = 2 * y0 - 1 + r, xi = 2 * x0 - 4 + col;
+                float v = 0.f;
+                if (yi >= 0 && yi < p.H && xi >= 0 && xi < p.W) v = in[((int64_t)c * p.H + yi) * p.W + xi];
+                s_in[i] = v;
+            }
+        }
     }
     __syncthreads();
-    const int ty = tid / ST_TX, tx = tid % ST_TX;
-    float acc[32];
+    const int ty = tid / ST_TX, tx = tid % ST_TX;                  // the thread's pixels: rows ty*PY + j, column tx
+    float acc[PY][32];
 #pragma unroll
-    for (int o = 0; o < 32; ++o) acc[o] = p.bias[o];
+    for (int j = 0; j < PY; ++j)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+        for (int o = 0; o < 32; ++o) acc[j][o] = p.bias[o];
+#pragma unroll
+    for (int ky = 0; ky < ((DBG & 2) ? 0 : 3); ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const float v = s_in[ci][2 * ty + ky][2 * tx + kx];
+            for (int ci = 0; ci < 3; ++ci) {                       // (ky, kx, ci) order: the fmaf chain of every output is fixed
                 const float* w = p.w + ((ky * 3 + kx) * 3 + ci) * 32;      // uniform address: scalar loads
+                float v[PY];
 #pragma unroll
-                for (int o = 0; o < 32; ++o) acc[o] = fmaf(v, w[o], acc[o]);
+                for (int j = 0; j < PY; ++j) v[j] = s_in[(ci * IR + 2 * (ty * PY + j) + ky) * ICP + 2 * tx + 3 + kx];      // x = 2*(x0 + tx) - 1 + kx
+#pragma unroll
+                for (int o = 0; o < 32; ++o)
+#pragma unroll
+                    for (int j = 0; j < PY; ++j) acc[j][o] = fmaf(v[j], w[o], acc[j][o]);
             }
-    if (BF16) {
-        __bf16* so = (__bf16*)s_out + tid * (OLD * 2);
-#pragma unroll
-        for (int o = 0; o < 32; ++o) so[o] = (__bf16)fmaxf(acc[o], 0.f);
-    } else {
-        float* so = s_out + tid * OLD;
-#pragma unroll
-        for (int o = 0; o < 32; o += 4) *(f32x4*)(so + o) = f32x4{fmaxf(acc[o], 0.f), fmaxf(acc[o + 1], 0.f), fmaxf(acc[o + 2], 0.f), fmaxf(acc[o + 3], 0.f)};
-    }
-    __syncthreads();
     constexpr int CPP = BF16 ? 4 : 8;                               // 16-byte chunks per pixel
-    for (int qd = tid; qd < NT * CPP; qd += NT) {
-        const int pix = qd / CPP, part = qd % CPP;
-        const int yo = y0 + pix / ST_TX, xo = x0 + pix % ST_TX;
-        if (yo < p.Ho && xo < p.Wo) {
-            const f32x4 v = *(const f32x4*)(s_out + pix * OLD + part * 4);
-            char* dst = (char*)p.out + ((((int64_t)n * p.Ho + yo) * p.Wo + xo) * 32) * (BF16 ? 2 : 4) + part * 16;
-            *(f32x4*)dst = v;
+#pragma unroll
+    for (int j = 0; j < PY; ++j) {
+        __syncthreads();                                            // the tile (input, or the previous pass's output) is dead: the space is re-used
+        if (BF16) {
+            __bf16* so = (__bf16*)s_out + tid * (OLD * 2);
+#pragma unroll
+            for (int o = 0; o < 32; ++o) so[o] = (__bf16)fmaxf(acc[j][o], 0.f);
+        } else {
+            float* so = s_out + tid * OLD;
+#pragma unroll
+            for (int o = 0; o < 32; o += 4) *(f32x4*)(so + o) = f32x4{fmaxf(acc[j][o], 0.f), fmaxf(acc[j][o + 1], 0.f), fmaxf(acc[j][o + 2], 0.f), fmaxf(acc[j][o + 3], 0.f)};
+        }
+        __syncthreads();
+        for (int qd = tid; qd < ((DBG & 4) ? 0 : NT * CPP); qd += NT) {
+            const int pix = qd / CPP, part = qd % CPP;                  // pixel = thread `pix`'s j-th: row (pix / 32) * PY + j
+            const int yo = y0 + (pix / ST_TX) * PY + j, xo = x0 + pix % ST_TX;
+            if (yo < p.Ho && xo < p.Wo) {
+                const f32x4 v = *(const f32x4*)(s_out + pix * OLD + part * 4);
+                char* dst = (char*)p.out + ((((int64_t)n * p.Ho + yo) * p.Wo + xo) * 32) * (BF16 ? 2 : 4) + part * 16;
+                *(f32x4*)dst = v;
+            }
         }
     }
 }
@@ -97,7 +137,15 @@ static hipError_t launch_stem_t(const StemParams& p, hipStream_t s) {
     const int tx = (p.Wo + ST_TX - 1) / ST_TX;
     int ty = ((int64_t)tx * ((p.Ho + 7) / 8) * p.N >= 2048) ? 8 : (((int64_t)tx * ((p.Ho + 3) / 4) * p.N >= 2048) ? 4 : 2);
     if (env) ty = atoi(env);
-    if (ty == 8) hipLaunchKernelGGL((stem_kernel<BF16, 8>), dim3(tx * ((p.Ho + 7) / 8), p.N), dim3(256), 0, s, p);
+#ifdef LWP_ABLATION
+    static const char* dbg = getenv("LWP_STEM_DEBUG");
+    const int d = dbg ? atoi(dbg) : 0;
+#define ST_DBG(D_) if (ty == 8 && d == D_) { hipLaunchKernelGGL((stem_kernel<BF16, 8, 1, D_>), dim3(tx * ((p.Ho + 7) / 8), p.N), dim3(256), 0, s, p); return hipGetLastError(); }
+    ST_DBG(1) ST_DBG(2) ST_DBG(4) ST_DBG(3) ST_DBG(5) ST_DBG(6) ST_DBG(7)
+#undef ST_DBG
+#endif
+    if (ty == 16) hipLaunchKernelGGL((stem_kernel<BF16, 8, 2>), dim3(tx * ((p.Ho + 15) / 16), p.N), dim3(256), 0, s, p);
+    else if (ty == 8) hipLaunchKernelGGL((stem_kernel<BF16, 8>), dim3(tx * ((p.Ho + 7) / 8), p.N), dim3(256), 0, s, p);
     else if (ty == 4) hipLaunchKernelGGL((stem_kernel<BF16, 4>), dim3(tx * ((p.Ho + 3) / 4), p.N), dim3(128), 0, s, p);
     else if (ty == 2) hipLaunchKernelGGL((stem_kernel<BF16, 2>), dim3(tx * ((p.Ho + 1) / 2), p.N), dim3(64), 0, s, p);
     else return hipErrorInvalidValue;

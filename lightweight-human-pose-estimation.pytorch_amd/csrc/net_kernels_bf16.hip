@@ -34,7 +34,8 @@ __device__ __forceinline__ float act_f(float v, int act) {
 // [BM][C] (f32 math on bf16 inputs) into LDS as bf16; phase 2 is a barrier-free GEMM with v_mfma_f32_16x16x32_bf16.
 // A lane (i = lane&15, q = lane>>4) reads 8 consecutive k (16 B) at k = 32s + 8q: exactly the operand lane map, for
 // the activation tile (from LDS) and for the fragment-packed weights [k-step][wave][tile][lane][8] (from L2) alike.
-template <int BM, int NW>
+// DBG (compile time; LWP_ABLATION builds only): 1 no depthwise phase, 2 no weight stream, 4 no MFMA, 8 no epilogue
+template <int BM, int NW, int DBG = 0>
 __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     constexpr int NT = NW * 64;
     constexpr int RT = BM / 16;
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     constexpr int PXG = 4;
     static_assert(BM % PXG == 0, "row block must hold whole pixel groups");
     const int cg = p.C >> 2;
-    {
+    if (!(DBG & 1)) {
         const int c = (tid % cg) * 4;
         f32x4 wv[9];
 #pragma unroll
@@ -162,10 +163,11 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
         for (int jb = 0; jb < PF; ++jb) {
             const int step = s0 + jb;
             if (step >= nsteps) break;
-            if (step + PF - 1 < nsteps) load_b(step + PF - 1, bw[(jb + PF - 1) % PF]);
+            if (step + PF - 1 < nsteps && !(DBG & 2)) load_b(step + PF - 1, bw[(jb + PF - 1) % PF]);
 #pragma unroll
             for (int a = 0; a < RT; ++a) {
                 const bf16x8 xv = *(const bf16x8*)(x_lane + a * 16 * ldA + step * 32);
+                if (DBG & 4) { asm volatile("" ::"v"(xv)); continue; }
                 acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[jb][0], xv, acc[a][0], 0, 0, 0);
                 acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[jb][1], xv, acc[a][1], 0, 0, 0);
             }
@@ -174,38 +176,62 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     // epilogue
     __bf16* out = (__bf16*)p.out;
     const __bf16* res = (const __bf16*)p.res;
+    if (DBG & 8) {
+        float sum = 0.f;
+#pragma unroll
+        for (int a = 0; a < RT; ++a) sum += acc[a][0][0] + acc[a][0][1] + acc[a][0][2] + acc[a][0][3] + acc[a][1][0] + acc[a][1][1] + acc[a][1][2] + acc[a][1][3];
+        if (sum == 12345.678f) out[0] = (__bf16)sum;
+        return;
+    }
+    // The tile goes through LDS (the depthwise tile is dead once every wave has left the K loop) so that the write-out is
+    // 16 bytes per lane on consecutive addresses: whole pixel rows of the workgroup's NW*32 channels.  The accumulator layout
+    // itself gives 8 bytes per lane at a 2*out_ld-byte stride, i.e. partial 128-byte lines: 30 us of the 143 us of a 512 -> 512
+    // block at batch 32 (ablation), 94 of the 186 us of model.1.
+    constexpr int WC = NW * 32;                      // channels of this workgroup
+    constexpr int OLD = WC + 8;                      // staged row stride (elements)
+    __bf16* Ot = (__bf16*)dsm_raw;                   // [BM][OLD]
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int n = wave * 32 + t * 16 + 4 * q;
+        const int nl = (tid >> 6) * 32 + t * 16 + 4 * q;             // channel within the workgroup's window
+        const int n = blockIdx.y * WC + nl;
         const f32x4 bias = *(const f32x4*)(p.pw_b + n);
 #pragma unroll
         for (int a = 0; a < RT; ++a) {
             const int64_t m = m0 + a * 16 + i16;
-            if (m < M) {
-                f32x4 v = acc[a][t] + bias;
-                v.x = act_f(v.x, p.act_pw); v.y = act_f(v.y, p.act_pw); v.z = act_f(v.z, p.act_pw); v.w = act_f(v.w, p.act_pw);
-                if (res) {
-                    const bf16x4 r = *(const bf16x4*)(res + m * p.res_ld + n);
-                    v.x += (float)r[0]; v.y += (float)r[1]; v.z += (float)r[2]; v.w += (float)r[3];
-                }
-                bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-                *(bf16x4*)(out + m * p.out_ld + n) = o;
+            f32x4 v = acc[a][t] + bias;
+            v.x = act_f(v.x, p.act_pw); v.y = act_f(v.y, p.act_pw); v.z = act_f(v.z, p.act_pw); v.w = act_f(v.w, p.act_pw);
+            if (res && m < M) {                      // residual before the (single) rounding to bf16
+                const bf16x4 r = *(const bf16x4*)(res + m * p.res_ld + n);
+                v.x += (float)r[0]; v.y += (float)r[1]; v.z += (float)r[2]; v.w += (float)r[3];
             }
+            const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+            *(bf16x4*)(Ot + (a * 16 + i16) * OLD + nl) = o;
         }
+    }
+    __syncthreads();
+    constexpr int CPR = WC / 8;                      // 16-byte chunks per pixel row
+    for (int ch = tid; ch < BM * CPR; ch += NT) {
+        const int row = ch / CPR, col = (ch - row * CPR) * 8;
+        const int64_t m = m0 + row;
+        if (m < M) *(bf16x8*)(out + m * p.out_ld + blockIdx.y * WC + col) = *(const bf16x8*)(Ot + row * OLD + col);
     }
 }
 
-template <int BM, int NW>
+template <int BM, int NW, int DBG = 0>
 static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
-    const size_t lds = (size_t)BM * (p.C + 8) * 2;
+    size_t lds = (size_t)BM * (p.C + 8) * 2;
+    const size_t lds_out = (size_t)BM * (NW * 32 + 8) * 2;          // the staged output tile re-uses the space
+    if (lds_out > lds) lds = lds_out;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int nsplit = (p.cout / 32) / NW;
     static LdsAttrOnce attr;
     if (lds > 48 * 1024) {
-        hipError_t e = attr.ensure((const void*)dwpw_bf16_kernel<BM, NW>, 160 * 1024);
+        hipError_t e = attr.ensure((const void*)dwpw_bf16_kernel<BM, NW, DBG>, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((dwpw_bf16_kernel<BM, NW>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
+    hipLaunchKernelGGL((dwpw_bf16_kernel<BM, NW, DBG>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }
 
@@ -218,9 +244,18 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
     if (M / 64 >= 1024 && nw >= 8) bm = 128;         // >= 256 output channels: halve the per-workgroup weight stream (measured 3-8 %)
     static const char* env = getenv("LWP_DWPW_BM");
     if (env) bm = atoi(env);
-    while (bm > 16 && (size_t)bm * (p.C + 8) * 2 > 150 * 1024) bm >>= 1;
+    while (bm > 16 && (size_t)bm * ((p.C > p.cout ? p.C : p.cout) + 8) * 2 > 150 * 1024) bm >>= 1;
     if (bm == 128 && nw < 4) bm = 64;
     // every thread must own a whole 8-channel chunk column: NW*64 threads must be a multiple of C/8 (always true here)
+#ifdef LWP_ABLATION
+    static const char* dbg = getenv("LWP_DWPWH_DEBUG");
+    const int d = dbg ? atoi(dbg) : 0;
+#define DPH_DBG(BM_, NW_, D_) if (bm == BM_ && nw == NW_ && d == D_) return launch_dwpw_bf16_t<BM_, NW_, D_>(p, s);
+#define DPH_DBGS(BM_, NW_) DPH_DBG(BM_, NW_, 1) DPH_DBG(BM_, NW_, 2) DPH_DBG(BM_, NW_, 4) DPH_DBG(BM_, NW_, 6) DPH_DBG(BM_, NW_, 7) DPH_DBG(BM_, NW_, 8) DPH_DBG(BM_, NW_, 14) DPH_DBG(BM_, NW_, 15)
+    DPH_DBGS(128, 16) DPH_DBGS(64, 2) DPH_DBGS(64, 4)
+#undef DPH_DBGS
+#undef DPH_DBG
+#endif
 #define DPH_CASE(BM_, NW_) if (bm == BM_ && nw == NW_) return launch_dwpw_bf16_t<BM_, NW_>(p, s);
     DPH_CASE(16, 2) DPH_CASE(32, 2) DPH_CASE(64, 2)
     DPH_CASE(16, 4) DPH_CASE(32, 4) DPH_CASE(64, 4)
