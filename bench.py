@@ -458,6 +458,35 @@ def measure_extras(out, args, eng, engines, net, sd, x, x_np, step, run_steps, l
         except Exception as e:                    # a measurement of a secondary config must not take the bench line down
             other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    def replicas(e0, dt_, count):
+        """`count` engines sharing e0's weights (device-to-device copy of the packed blob)."""
+        from lwpose_amd.models.with_mobilenet import PoseEstimationWithMobileNet
+        out_ = [e0]
+        if count > 1:
+            blob = torch.empty(e0.weights_blob_bytes(), dtype=torch.uint8, device=torch.device("cuda", local_rank))
+            e0.export_weights(blob)
+            for _ in range(count - 1):
+                n2 = PoseEstimationWithMobileNet(args.nref, dtype=dt_)
+                n2.eval().cuda(local_rank)
+                n2.engine.import_weights(blob)
+                out_.append(n2.engine)
+                _KEEP.append(n2)
+        return out_
+
+    def pipelined_steps(engs, xb, k):
+        """k complete passes through the two-slot streaming pipeline of every engine (the headline's protocol)."""
+        E, pending, r = len(engs), [], None
+        for i in range(k):
+            e, slot = engs[i % E], (i // E) & 1
+            if len(pending) >= 2 * E:
+                pe, ps = pending.pop(0)
+                r = pe.pipeline_fetch(ps)
+            e.pipeline_submit(xb, slot, 4, True)
+            pending.append((e, slot))
+        for pe, ps in pending:
+            r = pe.pipeline_fetch(ps)
+        return r
+
     def batched(b, dt_):
         def run():
             if dt_ == args.dtype:
@@ -467,6 +496,7 @@ def measure_extras(out, args, eng, engines, net, sd, x, x_np, step, run_steps, l
                 eng2 = net2.engine
                 _KEEP.append(net2)
             xb = torch.from_numpy(workload.normalized_input(synth.make_frames(b, args.height, args.width))).cuda(local_rank)
+            # serial steps (submit, wait, fetch) ...
             for _ in range(2):
                 eng2.infer_poses_async(xb, 4, True); rr = eng2.fetch_poses()
             ts = []
@@ -477,9 +507,22 @@ def measure_extras(out, args, eng, engines, net, sd, x, x_np, step, run_steps, l
                     eng2.infer_poses_async(xb, 4, True); rr = eng2.fetch_poses()
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t1) / 4)
+            t_serial = sorted(ts)[1]
+            # ... and the headline's protocol: two engine streams, two result slots each (grouping + fetch of a batch overlap
+            # the network of the next ones); every step is still a complete pass with its results on the host
+            engs = replicas(eng2, dt_, 2)
+            pipelined_steps(engs, xb, 4)
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                pipelined_steps(engs, xb, 8)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) / 8)
             t2 = sorted(ts)[1]
             dms = eng2.time_pipeline(xb, 5, what=1) / 5.0
-            ent = {"frames_per_s": b / t2, "ms_per_step": t2 * 1e3, "device_ms_per_step": dms,
+            ent = {"frames_per_s": b / t2, "ms_per_step": t2 * 1e3, "protocol": "2 engine streams x 2 result slots (as the headline)",
+                   "serial_frames_per_s": b / t_serial, "serial_ms_per_step": t_serial * 1e3, "device_ms_per_step": dms,
                    "poses_per_frame": float(np.mean([len(r[0]) for r in rr]))}
             if b == 32:
                 rf, cl, _ = class_rooflines(eng2, xb, b, args.height, args.width, dt_, dms)

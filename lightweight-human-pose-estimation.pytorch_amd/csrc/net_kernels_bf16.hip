@@ -29,6 +29,18 @@ __device__ __forceinline__ float act_f(float v, int act) {
 
 // (the stem kernel is the <true> instantiation of stem_kernel in net_kernels.hip)
 
+static int device_cu_count() {
+    static int cus[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
 // ---------------------------------------------------------------------------------------- fused depthwise -> pointwise
 // Same two-phase structure as the f32 kernel (net_kernels.hip): phase 1 computes the workgroup's depthwise row block
 // [BM][C] (f32 math on bf16 inputs) into LDS as bf16; phase 2 is a barrier-free GEMM with v_mfma_f32_16x16x32_bf16.
@@ -235,6 +247,15 @@ static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Measured and dropped (round 2, batch 32, 512 -> 512, two-phase kernel 143 us): a K-streamed form — persistent workgroups over
+// 8 x 16 pixel patches, the input window of every 64-channel chunk brought in by LDS-DMA (1.4x instead of 4.5x re-reads),
+// depthwise conv from LDS into a double-buffered [128][64] tile, v_mfma_f32_32x32x16_bf16 with the accumulators kept across
+// the chunks and a whole chunk of weights in flight.  (a) wave-specialised, 4 producer + 8 consumer waves, one barrier per
+// chunk: 190 us — a single producer wave per SIMD issues one VALU instruction per 4+ cycles (2.6 us per chunk against 1.6 us
+// of consumer time) and the two sides' times ADDED in every ablation; (b) symmetric, all 8 waves produce then multiply: 228 us —
+// depthwise from LDS at two waves per SIMD 104 us, and the in-order vmcnt makes the wave wait for its own output stores when
+// it next needs a DMA piece (63 us of "epilogue").  The depthwise conv is VALU-instruction-bound (~19 instructions per output
+// element in f32 on bf16 inputs), not load-bound: the lever that remains is fewer instructions (v_dot2_f32_bf16 on tap pairs).
 hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     const int nw = p.cout / 32;
@@ -758,18 +779,6 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
         }
         __syncthreads();                                    // the f32 tile has been read: the next tile's window may overwrite it
     }
-}
-
-static int device_cu_count() {
-    static int cus[kMaxDevices] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
-    if (!cus[dev]) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus[dev] = v;
-    }
-    return cus[dev];
 }
 
 static size_t gemm_bf16_ar_lds(const GemmParams& p, int BM) {
