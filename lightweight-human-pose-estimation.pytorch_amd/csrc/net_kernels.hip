@@ -207,7 +207,128 @@ __global__ void __launch_bounds__(256) dw_kernel(DwParams p) {
     }
 }
 
+// LDS-tiled depthwise kernel for large maps (batch 32): the per-thread kernel above fetches every input vector 6-9 times
+// through L1/L2 (2.2 TB/s of algorithmic traffic at batch 32 on the 512-channel layers: the L2 -> L1 path is the limit, not
+// HBM).  Here a workgroup owns an 8 x 8 patch of output pixels x CC channels (CC = 64, or 32 for the first block): the input
+// window ((7 s + 2 d + 1)^2 pixels x CC channels, 256-byte row pieces) is loaded ONCE with 16-byte loads into LDS — every input
+// byte is fetched (10/8)^2 = 1.56 times at stride 1 — and each thread walks a column strip of the patch (4 channels, RPT rows)
+// with a rolling 3 x 3 register window; the results leave as 16-byte stores, 256 contiguous bytes per pixel.  25-37 KB of LDS
+// per workgroup: 4-6 workgroups per CU overlap each other's load / compute / store phases.
+// Same arithmetic and summation order as dw_kernel (bias, then the nine taps row-major): bit-identical results.
+template <int CC, int S, int D>
+__global__ void __launch_bounds__(256) dw_tiled_kernel(DwParams p, int tiles_y, int tiles_x) {
+    constexpr int PH = 8, PW = 8;
+    constexpr int QN = CC / 4;                        // channel quads per chunk
+    constexpr int GRP = 256 / (QN * PW);              // row groups of the patch handled in parallel
+    constexpr int RPT = PH / GRP;                     // patch rows per thread
+    constexpr int WR = (PH - 1) * S + 2 * D + 1, WC = (PW - 1) * S + 2 * D + 1;
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.y, c0 = chunk * CC;
+    const int per_img = tiles_y * tiles_x;
+    const int n = blockIdx.x / per_img, r0 = blockIdx.x - n * per_img;
+    const int ty0 = (r0 / tiles_x) * PH, tx0 = (r0 % tiles_x) * PW;
+    const int y0 = ty0 * S - D, x0 = tx0 * S - D;     // input position of window (0, 0)
+    const float* img = p.in + (int64_t)n * p.Hi * p.Wi * p.in_ld + c0;
+    // ---- stage the window: piece = (window pixel, 16-byte part); all loads of a thread are issued before its stores
+    constexpr int NPIECE = WR * WC * QN, PPT = (NPIECE + 255) / 256;
+    f32x4 pc[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        const int i = tid + u * 256;
+        const int px = i / QN, part = i % QN;
+        const int wy = px / WC, wx = px % WC;
+        const int y = y0 + wy, x = x0 + wx;
+        const bool ok = i < NPIECE && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
+        pc[u] = ok ? *(const f32x4*)(img + ((int64_t)y * p.Wi + x) * p.in_ld + part * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int cq = tid % QN, lx = (tid / QN) % PW, grp = tid / (QN * PW);
+    const int c = c0 + cq * 4;
+    f32x4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = *(const f32x4*)(p.w + t * p.C + c);
+    const f32x4 b = *(const f32x4*)(p.bias + c);
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        const int i = tid + u * 256;
+        if (i < NPIECE) *(f32x4*)(dsm + (size_t)i * 4) = pc[u];      // piece order = [pixel][CC] row-major
+    }
+    __syncthreads();
+    const float* win = dsm + cq * 4;
+    const int xo = tx0 + lx;
+    auto at = [&](int wy, int wx) -> f32x4 { return *(const f32x4*)(win + (size_t)(wy * WC + wx) * CC); };
+    auto put = [&](f32x4 acc, int ly) {
+        const int yo = ty0 + ly;
+        if (yo < p.Ho && xo < p.Wo) {
+            acc.x = apply_act(acc.x, p.act); acc.y = apply_act(acc.y, p.act); acc.z = apply_act(acc.z, p.act); acc.w = apply_act(acc.w, p.act);
+            *(f32x4*)(p.out + (((int64_t)n * p.Ho + yo) * p.Wo + xo) * p.out_ld + c) = acc;
+        }
+    };
+    if (S == 1 && D == 1) {                            // rolling 3 x 3 window down the column strip: 3 LDS reads per output instead of 9
+        f32x4 r[3][3];
+        const int ly0 = grp * RPT;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) r[k + 1][kx] = at(ly0 + k, lx + kx);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) { r[0][kx] = r[1][kx]; r[1][kx] = r[2][kx]; r[2][kx] = at(ly0 + i + 2, lx + kx); }
+            f32x4 acc = b;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc += r[t / 3][t % 3] * w[t];
+            put(acc, ly0 + i);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int ly = grp * RPT + i;
+            f32x4 acc = b;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc += at(ly * S + (t / 3) * D, lx * S + (t % 3) * D) * w[t];
+            put(acc, ly);
+        }
+    }
+}
+
+template <int CC, int S, int D>
+static hipError_t launch_dw_tiled_t(const DwParams& p, hipStream_t s, int64_t tiles, int tiles_y, int tiles_x) {
+    constexpr int WR = 7 * S + 2 * D + 1;
+    constexpr size_t lds = (size_t)WR * WR * CC * sizeof(float);
+    static LdsAttrOnce attr;
+    if (lds > 48 * 1024) { hipError_t e = attr.ensure((const void*)dw_tiled_kernel<CC, S, D>, 96 * 1024); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL((dw_tiled_kernel<CC, S, D>), dim3((unsigned)tiles, p.C / CC), dim3(256), lds, s, p, tiles_y, tiles_x);
+    return hipGetLastError();
+}
+
+static hipError_t try_dw_tiled(const DwParams& p, hipStream_t s, bool* used) {
+    *used = false;
+    static const char* env = getenv("LWP_DW_TILED");         // "0": the per-thread kernel everywhere (A/B)
+    if (env && env[0] == '0') return hipSuccess;
+    const int64_t pixels = (int64_t)p.N * p.Ho * p.Wo;
+    if (pixels * p.C < (int64_t)8 * 1024 * 1024) return hipSuccess;       // small maps: the per-thread kernel fills the chip better
+    if ((p.stride != 1 && p.stride != 2) || (p.dil != 1 && p.dil != 2) || (p.in_ld & 3) || (p.out_ld & 3)) return hipSuccess;
+    if (p.stride == 2 && p.dil == 2) return hipSuccess;
+    const int cc = p.C % 64 == 0 ? 64 : (p.C % 32 == 0 ? 32 : 0);
+    if (!cc) return hipSuccess;
+    const int tiles_y = (p.Ho + 7) / 8, tiles_x = (p.Wo + 7) / 8;
+    const int64_t tiles = (int64_t)p.N * tiles_y * tiles_x;
+    if (tiles >= (1ll << 31) - 1 || p.C / cc > 65535) return hipSuccess;
+    *used = true;
+#define DT_CASE(CC_, S_, D_) if (cc == CC_ && p.stride == S_ && p.dil == D_) return launch_dw_tiled_t<CC_, S_, D_>(p, s, tiles, tiles_y, tiles_x);
+    DT_CASE(64, 1, 1) DT_CASE(64, 1, 2) DT_CASE(64, 2, 1) DT_CASE(32, 1, 1) DT_CASE(32, 1, 2) DT_CASE(32, 2, 1)
+#undef DT_CASE
+    *used = false;
+    return hipSuccess;
+}
+
 hipError_t launch_dw(const DwParams& p, hipStream_t s) {
+    {
+        bool used = false;
+        hipError_t e = try_dw_tiled(p, s, &used);
+        if (e != hipSuccess || used) return e;
+    }
     const int cg = p.C >> 2;
     // few pixels per thread when the map is small (keep the chip full), more when it is large
     const int64_t pixels = (int64_t)p.N * p.Ho * p.Wo;
