@@ -215,9 +215,9 @@ __global__ void __launch_bounds__(256) dw_kernel(DwParams p) {
 // with a rolling 3 x 3 register window; the results leave as 16-byte stores, 256 contiguous bytes per pixel.  25-37 KB of LDS
 // per workgroup: 4-6 workgroups per CU overlap each other's load / compute / store phases.
 // Same arithmetic and summation order as dw_kernel (bias, then the nine taps row-major): bit-identical results.
-template <int CC, int S, int D>
+template <int CC, int S, int D, int PH>
 __global__ void __launch_bounds__(256) dw_tiled_kernel(DwParams p, int tiles_y, int tiles_x) {
-    constexpr int PH = 8, PW = 8;
+    constexpr int PW = 8;
     constexpr int QN = CC / 4;                        // channel quads per chunk
     constexpr int GRP = 256 / (QN * PW);              // row groups of the patch handled in parallel
     constexpr int RPT = PH / GRP;                     // patch rows per thread
@@ -280,6 +280,25 @@ __global__ void __launch_bounds__(256) dw_tiled_kernel(DwParams p, int tiles_y, 
             for (int t = 0; t < 9; ++t) acc += r[t / 3][t % 3] * w[t];
             put(acc, ly0 + i);
         }
+    } else if (S == 1 && D == 2 && RPT >= 2 && RPT % 2 == 0) {      // dilation 2: two interleaved rolling windows (even / odd rows)
+        const int ly0 = grp * RPT;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            f32x4 r[3][3];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) r[k + 1][kx] = at(ly0 + par + 2 * k, lx + 2 * kx);
+#pragma unroll
+            for (int i = par; i < RPT; i += 2) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) { r[0][kx] = r[1][kx]; r[1][kx] = r[2][kx]; r[2][kx] = at(ly0 + i + 4, lx + 2 * kx); }
+                f32x4 acc = b;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc += r[t / 3][t % 3] * w[t];
+                put(acc, ly0 + i);
+            }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
@@ -292,13 +311,16 @@ __global__ void __launch_bounds__(256) dw_tiled_kernel(DwParams p, int tiles_y, 
     }
 }
 
-template <int CC, int S, int D>
-static hipError_t launch_dw_tiled_t(const DwParams& p, hipStream_t s, int64_t tiles, int tiles_y, int tiles_x) {
-    constexpr int WR = 7 * S + 2 * D + 1;
-    constexpr size_t lds = (size_t)WR * WR * CC * sizeof(float);
+template <int CC, int S, int D, int PH>
+static hipError_t launch_dw_tiled_t(const DwParams& p, hipStream_t s) {
+    constexpr int WR = (PH - 1) * S + 2 * D + 1, WC = 7 * S + 2 * D + 1;
+    constexpr size_t lds = (size_t)WR * WC * CC * sizeof(float);
+    const int tiles_y = (p.Ho + PH - 1) / PH, tiles_x = (p.Wo + 7) / 8;
+    const int64_t tiles = (int64_t)p.N * tiles_y * tiles_x;
+    if (tiles >= (1ll << 31) - 1) return hipErrorInvalidValue;
     static LdsAttrOnce attr;
-    if (lds > 48 * 1024) { hipError_t e = attr.ensure((const void*)dw_tiled_kernel<CC, S, D>, 96 * 1024); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL((dw_tiled_kernel<CC, S, D>), dim3((unsigned)tiles, p.C / CC), dim3(256), lds, s, p, tiles_y, tiles_x);
+    if (lds > 48 * 1024) { hipError_t e = attr.ensure((const void*)dw_tiled_kernel<CC, S, D, PH>, 96 * 1024); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL((dw_tiled_kernel<CC, S, D, PH>), dim3((unsigned)tiles, p.C / CC), dim3(256), lds, s, p, tiles_y, tiles_x);
     return hipGetLastError();
 }
 
@@ -312,11 +334,13 @@ static hipError_t try_dw_tiled(const DwParams& p, hipStream_t s, bool* used) {
     if (p.stride == 2 && p.dil == 2) return hipSuccess;
     const int cc = p.C % 64 == 0 ? 64 : (p.C % 32 == 0 ? 32 : 0);
     if (!cc) return hipSuccess;
-    const int tiles_y = (p.Ho + 7) / 8, tiles_x = (p.Wo + 7) / 8;
-    const int64_t tiles = (int64_t)p.N * tiles_y * tiles_x;
-    if (tiles >= (1ll << 31) - 1 || p.C / cc > 65535) return hipSuccess;
+    if (p.C / cc > 65535 || pixels >= (1ll << 31)) return hipSuccess;
+    // 16-row patches pay on the first block only (32 channels: 128-byte pixel rows, 30k workgroups): 4.05 -> 5.09 TB/s; the
+    // 46 x 82 layers lose with them (cpm.trunk 4.6 -> 3.7 TB/s)
+    static const char* phenv = getenv("LWP_DW_PH");           // patch rows 8 | 16 (experiments)
+    const int ph = phenv ? atoi(phenv) : (cc == 32 ? 16 : 8);
     *used = true;
-#define DT_CASE(CC_, S_, D_) if (cc == CC_ && p.stride == S_ && p.dil == D_) return launch_dw_tiled_t<CC_, S_, D_>(p, s, tiles, tiles_y, tiles_x);
+#define DT_CASE(CC_, S_, D_) if (cc == CC_ && p.stride == S_ && p.dil == D_) return ph == 16 && S_ == 1 ? launch_dw_tiled_t<CC_, S_, D_, 16>(p, s) : launch_dw_tiled_t<CC_, S_, D_, 8>(p, s);
     DT_CASE(64, 1, 1) DT_CASE(64, 1, 2) DT_CASE(64, 2, 1) DT_CASE(32, 1, 1) DT_CASE(32, 1, 2) DT_CASE(32, 2, 1)
 #undef DT_CASE
     *used = false;
