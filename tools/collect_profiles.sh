@@ -6,29 +6,46 @@ OUT=${1:-gpurun_out/profiles}
 ROOT=$(pwd)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs"
-# 1. kernel trace + stats of the default bench configuration (two streams) and of the single-stream run
+B="python3 $ROOT/bench.py --steps 50 --warmup 5 --min-time 0.2 --no-cpu-baseline --no-extra-configs"
+# 1. kernel trace + stats of the default bench configuration (three streams) and of the single-stream run
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/rp_default -- $B > $ROOT/$OUT/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/rp_single -- $B --streams 1 > $ROOT/$OUT/bench_under_rocprof_single_stream.json 2>/dev/null
-cp $ROOT/$OUT/rp_default/*/*_kernel_stats.csv $ROOT/$OUT/kernel_stats_b1_fp32_two_streams.csv
+cp $ROOT/$OUT/rp_default/*/*_kernel_stats.csv $ROOT/$OUT/kernel_stats_b1_fp32_three_streams.csv
 cp $ROOT/$OUT/rp_single/*/*_kernel_stats.csv $ROOT/$OUT/kernel_stats_b1_fp32_single_stream.csv
 rm -rf $ROOT/$OUT/rp_default $ROOT/$OUT/rp_single
+echo "kernel stats done"
+# 1b. kernel stats of the batch-32 configurations (single stream)
+for cfg in "b32_fp32:--batch 32 --steps 4" "b32_bf16:--batch 32 --dtype bf16 --steps 4"; do
+  tag=${cfg%%:*}; fl=${cfg#*:}
+  rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/rp_$tag -- python3 $ROOT/bench.py --streams 1 $fl --warmup 1 --preroll 0 --min-time 0.1 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  cp $ROOT/$OUT/rp_$tag/*/*_kernel_stats.csv $ROOT/$OUT/kernel_stats_${tag}_single_stream.csv
+  rm -rf $ROOT/$OUT/rp_$tag
+done
+echo "batch-32 kernel stats done"
 # 2. HBM-side traffic counters, one pass each (never together with other trace domains)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_fetch -- $B --streams 1 --steps 20 --preroll 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_write -- $B --streams 1 --steps 20 --preroll 0 > /dev/null 2>&1
-cd $ROOT
-python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic_b1_fp32.json "batch=1 368x656 fp32 nref=1, bench.py --streams 1" > /dev/null
-rm -rf $OUT/pmc_fetch $OUT/pmc_write
+for cfg in "b1_fp32:--batch 1 --steps 20" "b32_fp32:--batch 32 --steps 3" "b32_bf16:--batch 32 --dtype bf16 --steps 3"; do
+  tag=${cfg%%:*}; fl=${cfg#*:}
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ROOT/$OUT/pmc_fetch -- python3 $ROOT/bench.py --streams 1 $fl --warmup 1 --preroll 0 --min-time 0.05 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ROOT/$OUT/pmc_write -- python3 $ROOT/bench.py --streams 1 $fl --warmup 1 --preroll 0 --min-time 0.05 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  (cd $ROOT && python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic_$tag.json "$tag 368x656 nref=1, bench.py --streams 1 $fl" > /dev/null)
+  rm -rf $ROOT/$OUT/pmc_fetch $ROOT/$OUT/pmc_write
+  echo "pmc traffic $tag done"
+done
 # 2b. matrix-pipe utilisation (its own pass)
 for cfg in "b1_fp32:--batch 1 --steps 20" "b32_fp32:--batch 32 --steps 4" "b32_bf16:--batch 32 --dtype bf16 --steps 4"; do
   tag=${cfg%%:*}; fl=${cfg#*:}
-  (cd /tmp && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $ROOT/$OUT/pmc_mfma -- python3 $ROOT/bench.py --streams 1 $fl --warmup 1 --preroll 0 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1)
-  python3 tools/pmc_mfma.py $OUT/pmc_mfma $OUT/mfma_util_$tag.txt "$tag" > /dev/null
-  rm -rf $OUT/pmc_mfma
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $ROOT/$OUT/pmc_mfma -- python3 $ROOT/bench.py --streams 1 $fl --warmup 1 --preroll 0 --min-time 0.05 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  (cd $ROOT && python3 tools/pmc_mfma.py $OUT/pmc_mfma $OUT/mfma_util_$tag.txt "$tag" > /dev/null)
+  rm -rf $ROOT/$OUT/pmc_mfma
+  echo "mfma util $tag done"
 done
-# 3. per-launch tables (HIP events) and the un-profiled bench line
+cd $ROOT
+# 3. per-launch tables (HIP events), the depthwise / stem roofline, the bf16 agreement figures and the un-profiled bench line
 python3 tools/profile_layers.py --batch 1 > $OUT/launch_table_b1_fp32.txt 2>/dev/null
 python3 tools/profile_layers.py --batch 32 > $OUT/launch_table_b32_fp32.txt 2>/dev/null
 python3 tools/profile_layers.py --batch 32 --dtype bf16 > $OUT/launch_table_b32_bf16.txt 2>/dev/null
+python3 tools/dw_roofline.py 32 > $OUT/depthwise_roofline_b32_fp32.txt 2>/dev/null
+python3 tools/bf16_agreement.py 4 > $OUT/bf16_agreement.json 2>/dev/null
+echo "tables done"
 python3 bench.py > $OUT/bench_default.json 2>/dev/null
 echo done

@@ -25,10 +25,12 @@ def kernel_class(name):
     if "gemm" in name:
         m = re.search(r"<([^>]*)>", name)
         args = [a.strip() for a in m.group(1).split(",")] if m else []
-        if "bf16" in name:
-            return "gemm_bf16"
+        if "gemm_bf16_ar" in name:                 # window-resident bf16 kernel: the dense 3x3 convs at large M
+            return "dense_3x3"
+        if "bf16" in name:                         # shared-tile bf16 kernel: the 1x1 convs (and 3x3 at small M)
+            return "gemm_1x1"
         return "dense_3x3" if args and args[-1] == "3" else "gemm_1x1"
-    if "dw_kernel" in name:
+    if "dw_kernel" in name or "dw_tiled" in name:
         return "depthwise"
     if any(k in name for k in ("find_peaks", "nms", "score_pairs", "match", "assemble", "publish", "preprocess", "upsample", "resize")):
         return "post"
