@@ -329,7 +329,8 @@ static hipError_t try_dw_tiled(const DwParams& p, hipStream_t s, bool* used) {
     static const char* env = getenv("LWP_DW_TILED");         // "0": the per-thread kernel everywhere (A/B)
     if (env && env[0] == '0') return hipSuccess;
     const int64_t pixels = (int64_t)p.N * p.Ho * p.Wo;
-    if (pixels * p.C < (int64_t)8 * 1024 * 1024) return hipSuccess;       // small maps: the per-thread kernel fills the chip better
+    const bool force = env && env[0] == '1';                  // "1": the tiled kernel at every size (tests)
+    if (!force && pixels * p.C < (int64_t)8 * 1024 * 1024) return hipSuccess;       // small maps: the per-thread kernel fills the chip better
     if ((p.stride != 1 && p.stride != 2) || (p.dil != 1 && p.dil != 2) || (p.in_ld & 3) || (p.out_ld & 3)) return hipSuccess;
     if (p.stride == 2 && p.dil == 2) return hipSuccess;
     const int cc = p.C % 64 == 0 ? 64 : (p.C % 32 == 0 ? 32 : 0);

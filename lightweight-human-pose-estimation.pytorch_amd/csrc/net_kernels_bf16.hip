@@ -828,7 +828,8 @@ static hipError_t try_gemm_bf16_ar(const GemmParams& p, hipStream_t s, bool* use
     if ((p.out_ld & 7) || (((uintptr_t)p.out) & 15) || (p.in_ld & 7) || (((uintptr_t)p.in) & 15)) return hipSuccess;
     if (p.res && ((p.res_ld & 7) || (((uintptr_t)p.res) & 15))) return hipSuccess;
     if (p.dil * (p.W + 1) > 180) return hipSuccess;           // the kernel's register budget for the window block held in registers
-    if (M < 128 * 256) return hipSuccess;                     // small problems: the shared-tile kernel's 64 x 64 tiles fill the chip better
+    static const char* fenv = getenv("LWP_GEMMH_AR_FORCE");  // "1": the window-resident kernel at every size (tests)
+    if (!(fenv && fenv[0] == '1') && M < 128 * 256) return hipSuccess;      // small problems: the shared-tile kernel's 64 x 64 tiles fill the chip better
     int bm = 0, wm = 0, wn = 0, bd = 0;
     if (!(env && sscanf(env, "%d,%d,%d,%d", &bm, &wm, &wn, &bd) == 4)) {
         // (128-row tiles, two workgroups per CU, measured slower at batch 32: 64.9 us against 44.3 for 256 rows, dilation 1)

@@ -829,3 +829,51 @@ def test_coco_detections_loop_vs_oracle():
         for kp, sc in zip(kps, scores):
             want.append({"image_id": int(s["file_name"][:-4]), "category_id": 1, "keypoints": [float(v) for v in kp], "score": float(sc)})
     assert len(want) >= 2 and got == want
+
+
+# ------------------------------------------------------------------------------------------ large-M kernels at small, ragged sizes
+def test_tiled_depthwise_kernel_forced_at_small_ragged_sizes(monkeypatch):
+    """dw_tiled_kernel (the batch-32 stand-alone depthwise path: 8 x 8 / 16 x 8 patches through LDS, rolling windows) forced
+    at sizes whose maps are not multiples of the patch: every depthwise layer (stride 1 / 2, dilation 1 / 2, 32..512
+    channels, ReLU and ELU) against the oracle's taps, and bit-identical to the per-thread kernel."""
+    monkeypatch.setenv("LWP_FUSE_DWPW", "0")
+    sd = synth.make_state_dict(1, seed=1)
+    x = net_input(2, 92, 150, seed=400)[:, :, :91, :149].copy()
+    taps = {}
+    net_ref.forward(sd, torch.from_numpy(x), 1, taps)
+
+    def run(tiled):
+        monkeypatch.setenv("LWP_DW_TILED", tiled)
+        net = PoseEstimationWithMobileNet(num_refinement_stages=1)
+        load_state(net, {"state_dict": sd})
+        net.eval().cuda()
+        return {i["name"]: net.engine.debug_layer_output(x, i["index"]) for i in net.engine.layers() if i["name"].endswith(".dw")}, net(x)
+    forced, outs_f = run("1")
+    plain, outs_p = run("0")
+    assert len(forced) == 14
+    for nm, got in forced.items():
+        ref = taps[nm].numpy()
+        assert np.abs(got - ref).max() <= NET_TOL * max(1.0, float(np.abs(ref).max())), nm
+        assert np.array_equal(got, plain[nm]), nm                  # same arithmetic, same order
+    for a, b in zip(outs_f, outs_p):
+        assert np.array_equal(a, b)
+
+
+def test_bf16_window_resident_gemm_forced_at_small_ragged_sizes(monkeypatch):
+    """gemm_bf16_ar_kernel (dense 3x3, batch-32 path: persistent 256-row tiles, window in LDS, dilation 1 and 2, residual)
+    forced at M = 2 x 12 x 19 = 456 pixels (not a multiple of the tile, tiles crossing the frame boundary): stage outputs within
+    the documented bf16 tolerance of the oracle, and close to the shared-tile bf16 kernel's."""
+    sd = synth.make_state_dict(1, seed=1)
+    x = net_input(2, 92, 150, seed=400)[:, :, :91, :149].copy()
+    ref = net_ref.forward(sd, torch.from_numpy(x), 1)
+
+    def run(force):
+        monkeypatch.setenv("LWP_GEMMH_AR_FORCE", force)
+        net = PoseEstimationWithMobileNet(num_refinement_stages=1, dtype="bf16")
+        load_state(net, {"state_dict": sd})
+        return net.eval().cuda()(x)
+    forced, plain = run("1"), run("0")
+    for f, q, r in zip(forced, plain, ref):
+        sc = max(1.0, float(r.abs().max()))
+        assert np.abs(f - r.numpy()).max() <= BF16_TOL * sc and np.abs(f - r.numpy()).mean() <= BF16_MEAN * sc
+        assert np.abs(f - q).max() <= BF16_TOL * sc            # same bf16 inputs, different summation order only
