@@ -510,7 +510,7 @@ def measure_extras(out, args, eng, engines, net, sd, x, x_np, step, run_steps, l
             t_serial = sorted(ts)[1]
             # ... and the headline's protocol: two engine streams, two result slots each (grouping + fetch of a batch overlap
             # the network of the next ones); every step is still a complete pass with its results on the host
-            engs = replicas(eng2, dt_, 2)
+            engs = replicas(eng2, dt_, int(os.environ.get("LWP_BENCH_BN_STREAMS", "2")))
             pipelined_steps(engs, xb, 4)
             ts = []
             for _ in range(3):
@@ -521,7 +521,7 @@ def measure_extras(out, args, eng, engines, net, sd, x, x_np, step, run_steps, l
                 ts.append((time.perf_counter() - t1) / 8)
             t2 = sorted(ts)[1]
             dms = eng2.time_pipeline(xb, 5, what=1) / 5.0
-            ent = {"frames_per_s": b / t2, "ms_per_step": t2 * 1e3, "protocol": "2 engine streams x 2 result slots (as the headline)",
+            ent = {"frames_per_s": b / t2, "ms_per_step": t2 * 1e3, "protocol": "%d engine stream(s) x 2 result slots (as the headline)" % len(engs),
                    "serial_frames_per_s": b / t_serial, "serial_ms_per_step": t_serial * 1e3, "device_ms_per_step": dms,
                    "poses_per_frame": float(np.mean([len(r[0]) for r in rr]))}
             if b == 32:

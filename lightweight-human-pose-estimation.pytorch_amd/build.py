@@ -20,7 +20,8 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-u
 EXTRA = {"post_kernels.hip": ["-ffp-contract=off"] + (["-DLWP_ASM_STAMPS"] if os.environ.get("LWP_ASM_STAMPS") else []),
          # LWP_ABLATION=1 at build time adds the ablation instantiations of the hot kernels (tools/ only; never shipped by default)
          "net_kernels_bf16.hip": (["-DLWP_ABLATION"] if os.environ.get("LWP_ABLATION") else []),
-         "net_kernels.hip": (["-DLWP_ABLATION"] if os.environ.get("LWP_ABLATION") else [])}
+         "net_kernels.hip": (["-DLWP_ABLATION"] if os.environ.get("LWP_ABLATION") else []) +
+                            (["-DDWPW_PF=%d" % int(os.environ["LWP_DWPW_PF"])] if os.environ.get("LWP_DWPW_PF") else [])}
 
 
 def _stale():

@@ -1078,7 +1078,10 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 
     // weight fragments: PF statically rotated register buffers (the K loop is unrolled by PF, no register copies), so
     // PF-1 steps of the weight stream stay in flight per wave (bandwidth-delay: ~250 KB must be in flight per CU)
-    constexpr int PF = 2;
+#ifndef DWPW_PF
+#define DWPW_PF 2
+#endif
+    constexpr int PF = DWPW_PF;
     f32x4 bw[PF][4];
     auto load_b = [&](int step, f32x4* dst) {
         const float* src = p.pw_w + ((int64_t)(step * nwt + wave) * 4) * 256 + lane * 4;
