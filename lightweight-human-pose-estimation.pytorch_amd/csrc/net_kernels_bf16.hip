@@ -47,7 +47,7 @@ static int device_cu_count() {
 // A lane (i = lane&15, q = lane>>4) reads 8 consecutive k (16 B) at k = 32s + 8q: exactly the operand lane map, for
 // the activation tile (from LDS) and for the fragment-packed weights [k-step][wave][tile][lane][8] (from L2) alike.
 // DBG (compile time; LWP_ABLATION builds only): 1 no depthwise phase, 2 no weight stream, 4 no MFMA, 8 no epilogue
-template <int BM, int NW, int DBG = 0>
+template <int BM, int NW, int DBG = 0, int SDIL = 1>
 __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     constexpr int NT = NW * 64;
     constexpr int RT = BM / 16;
@@ -101,15 +101,50 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
             const bf16x4 o = {(__bf16)act_f(a.x, p.act_dw), (__bf16)act_f(a.y, p.act_dw), (__bf16)act_f(a.z, p.act_dw), (__bf16)act_f(a.w, p.act_dw)};
             *(bf16x4*)(At + row * ldA + c) = o;
         };
+        // dilation 2 (model.7): the 3 x (PXG + 4) window does not fit the 128-VGPR cap of the 16-wave workgroups, so the group
+        // walks it one input row at a time — PXG + 2 dil loads per row added into the PXG accumulators before the next row is
+        // touched (6 loads per output pixel instead of 9, one row of vectors live). Same summation order as the general path:
+        // bias, then the nine taps row-major. (The same row-wise walk with 8-pixel groups at dilation 1 was measured 40-90 %
+        // SLOWER than the whole-window code below: the accumulator array defeats the load/FMA overlap the compiler finds there.)
+        auto shared_rows = [&](auto DIL_, const __bf16* base, int yo, int xo, int row0) {
+            constexpr int DIL = decltype(DIL_)::value;
+            constexpr int NV = PXG + 2 * DIL;
+            f32x4 a[PXG];
+#pragma unroll
+            for (int i = 0; i < PXG; ++i) a[i] = bias;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = yo + (ky - 1) * DIL;
+                const bool rok = yy >= 0 && yy < p.Hi;
+                bf16x4 rw[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int xx = xo + j - DIL;
+                    const __bf16* src = (rok && xx >= 0 && xx < p.Wi) ? base + ((int64_t)(ky - 1) * DIL * p.Wi + (j - DIL)) * p.in_ld : (const __bf16*)p.zeros;
+                    rw[j] = *(const bf16x4*)src;
+                }
+#pragma unroll
+                for (int i = 0; i < PXG; ++i)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bf16x4 w4 = rw[i + kx * DIL];
+                        const f32x4 v = {(float)w4[0], (float)w4[1], (float)w4[2], (float)w4[3]};
+                        a[i] += v * wv[ky * 3 + kx];
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < PXG; ++i) finish(a[i], row0 + i);
+        };
         for (int grp = tid / cg; grp < BM / PXG; grp += NT / cg) {
             const int row0 = grp * PXG;
             const int64_t m = m0 + row0;
             const int64_t mm = m < M ? m : 0;
             const int xo = (int)(mm % p.Wo), yo = (int)((mm / p.Wo) % p.Ho);
             const int64_t img = mm / ((int64_t)p.Wo * p.Ho);
-            if (p.stride == 1 && p.dil == 1 && m + PXG <= M && xo + PXG <= p.Wo) {
+            if (p.stride == 1 && m + PXG <= M && xo + PXG <= p.Wo && p.dil == SDIL) {
                 const __bf16* base = in + ((img * p.Hi + yo) * p.Wi + xo) * p.in_ld + c;
-                bf16x4 win[3][PXG + 2];                 // shared 3 x (PXG + 2) input window
+                if constexpr (SDIL == 2) { shared_rows(std::integral_constant<int, 2>{}, base, yo, xo, row0); continue; }
+                bf16x4 win[3][PXG + 2];                 // dilation 1: the whole 3 x (PXG + 2) window fits the register budget
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int yy = yo + ky - 1;
@@ -134,8 +169,6 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
                 }
                 continue;
             }
-            // (a shared window for dilation 2 was tried: its 24 live vectors spill at the 128-VGPR cap of the 16-wave
-            //  workgroups and slowed every layer by 30-40 %)
 #pragma unroll 1
             for (int i = 0; i < PXG; ++i) {           // general path: borders of the row block, stride 2, dilation 2
                 const int64_t mi = m0 + row0 + i;
@@ -230,7 +263,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     }
 }
 
-template <int BM, int NW, int DBG = 0>
+template <int BM, int NW, int DBG = 0, int SDIL = 1>
 static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     size_t lds = (size_t)BM * (p.C + 8) * 2;
@@ -240,10 +273,10 @@ static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     const int nsplit = (p.cout / 32) / NW;
     static LdsAttrOnce attr;
     if (lds > 48 * 1024) {
-        hipError_t e = attr.ensure((const void*)dwpw_bf16_kernel<BM, NW, DBG>, 160 * 1024);
+        hipError_t e = attr.ensure((const void*)dwpw_bf16_kernel<BM, NW, DBG, SDIL>, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((dwpw_bf16_kernel<BM, NW, DBG>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
+    hipLaunchKernelGGL((dwpw_bf16_kernel<BM, NW, DBG, SDIL>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }
 
@@ -277,6 +310,11 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
 #undef DPH_DBGS
 #undef DPH_DBG
 #endif
+    // the dilation-2 layer (model.7, 512 -> 512) gets its own instantiation: carrying both shared-window forms in one kernel
+    // spills 38 VGPRs at the 128-VGPR cap of the 16-wave workgroups
+#define DPH_DIL2(BM_) if (bm == BM_ && nw == 16 && p.dil == 2 && p.stride == 1) return launch_dwpw_bf16_t<BM_, 16, 0, 2>(p, s);
+    DPH_DIL2(16) DPH_DIL2(32) DPH_DIL2(64) DPH_DIL2(128)
+#undef DPH_DIL2
 #define DPH_CASE(BM_, NW_) if (bm == BM_ && nw == NW_) return launch_dwpw_bf16_t<BM_, NW_>(p, s);
     DPH_CASE(16, 2) DPH_CASE(32, 2) DPH_CASE(64, 2)
     DPH_CASE(16, 4) DPH_CASE(32, 4) DPH_CASE(64, 4)
