@@ -17,6 +17,7 @@
 namespace lwp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -1053,7 +1054,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
 //            never touches LDS: it is packed on the host in fragment order [k-step][wave][4][lane][4 floats], so each
 //            wave streams its own 4 KiB per 32-deep step from L2 with four fully coalesced 1-KiB loads, prefetched
 //            one step ahead in registers.  With 4 waves per SIMD and no barrier the matrix pipes stay fed.
-template <int BM, int NW>
+template <int BM, int NW, int DBG = 0>
 __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
     constexpr int NT = NW * 64;
     constexpr int RT = BM / 16;                      // row tiles per wave
@@ -1063,13 +1064,15 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = blockIdx.y * NW + (tid >> 6);   // global column-wave index (blockIdx.y: column split)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.pw_w, 0, 0x7fffffff, 0x00020000);
     const int nwt = gridDim.y * NW;                  // column waves in total = cout / 32
     const int r16 = lane & 15, q = lane >> 4;
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs): give every XCD a contiguous run of row
     // blocks, so that the 3-row input windows of neighbouring blocks are fetched into ONE L2 instead of all eight
     int bid = blockIdx.x;
-    if (gridDim.y == 1 && !(p.debug & 8)) {
+    if (gridDim.y == 1 && !(DBG & 8)) {
         const int nwg = gridDim.x, qq = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
         bid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
     }
@@ -1083,14 +1086,19 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 #endif
     constexpr int PF = DWPW_PF;
     f32x4 bw[PF][4];
+    f32x4 bx[(DBG & 32) ? PF : 1][4];
     auto load_b = [&](int step, f32x4* dst) {
-        const float* src = p.pw_w + ((int64_t)(step * nwt + wave) * 4) * 256 + lane * 4;
+        // buffer loads: the weights' descriptor and the step's offset are wave-uniform (SGPRs), a lane supplies one 32-bit offset
+        // register; the global_load form needs a 64-bit address per lane
+        const unsigned soff = (DBG & 16) ? (unsigned)(step & 1) * 4096u                  // ablation: every wave re-reads the same 8 KiB (L1 hits)
+                                         : (unsigned)(step * nwt + wave_u) * 4096u;
+        const int nld = (DBG & 64) ? 2 : 4;                                             // ablation 64: half the bytes in half the instructions
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = *(const f32x4*)(src + j * 256);
+        for (int j = 0; j < nld; ++j)
+            dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + j * 1024, soff, 0));
     };
 #pragma unroll
-    for (int j = 0; j < PF - 1; ++j)
-        if (j < nsteps) load_b(j, bw[j]);            // in flight during phase 1
+    for (int j = 0; j < PF - 1; ++j) load_b(j < nsteps ? j : nsteps - 1, bw[j]);   // in flight during phase 1
 
     // ---- phase 1: depthwise row block.  A thread keeps ONE 4-channel chunk (its 9 weight vectors + bias are loaded
     // once; NT is a multiple of C/4 for every layer shape) and walks groups of PXG consecutive output pixels.  When the
@@ -1099,7 +1107,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
     constexpr int PXG = 2;
     static_assert(BM % PXG == 0, "row block must hold whole pixel groups");
     const int cg = p.C >> 2;
-    if (!(p.debug & 1)) {
+    if (!(DBG & 1)) {
         const int c = (tid % cg) * 4;
         f32x4 wv[9];
 #pragma unroll
@@ -1170,34 +1178,58 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 #pragma unroll
     for (int a = 0; a < RT; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float* a_lane = At + r16 * ldA + 4 * q;
-    for (int s0 = 0; s0 < nsteps; s0 += PF) {
+    // one K step: request step + PF - 1 (past the end: the last step again — the loads are UNCONDITIONAL and the ring
+    // index static, so that the compiler can count the loads in flight: with a branch around them it waits for
+    // vmcnt(0), i.e. for the step it has just requested, and nothing of a wave's weight stream overlaps its own MFMAs)
+    auto one = [&](int step, auto P_) {
+        constexpr int P = decltype(P_)::value;
+        const int nxt = step + PF - 1 < nsteps ? step + PF - 1 : nsteps - 1;
+        if (DBG & 256) {                              // ablation: the stream goes to LDS by LDS-DMA (no VGPR destination), never read
+            const float* src = p.pw_w + ((int64_t)(nxt * nwt + wave) * 4) * 256 + lane * 4;
+            __attribute__((address_space(3))) float* wl = (__attribute__((address_space(3))) float*)(At + BM * ldA) + (tid >> 6) * 1024;
 #pragma unroll
-        for (int jb = 0; jb < PF; ++jb) {
-            const int step = s0 + jb;
-            if (step >= nsteps) break;
-            if (step + PF - 1 < nsteps && !(p.debug & 2)) load_b(step + PF - 1, bw[(jb + PF - 1) % PF]);
-            if (p.debug & 4) continue;
-            const f32x4* bcur = bw[jb];
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(src + j * 256, wl + j * 256, 16, 0, 0);
+        } else
+        if (DBG & 32) load_b(nxt, bx[(P + PF - 1) % PF]);   // ablation: the stream is requested but never waited for
+        else if (!(DBG & 2)) load_b(nxt, bw[(P + PF - 1) % PF]);
+        __builtin_amdgcn_sched_barrier(0);           // the scheduler otherwise sinks the requests below the MFMAs of this step
+        if (DBG & 4) return;
+        const f32x4* bcur = bw[P];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f32x4 av[RT];
+        for (int u = 0; u < 2; ++u) {
+            f32x4 av[RT];
 #pragma unroll
-                for (int a = 0; a < RT; ++a) av[a] = *(const f32x4*)(a_lane + a * 16 * ldA + step * 32 + 16 * u);
+            for (int a = 0; a < RT; ++a) av[a] = *(const f32x4*)(a_lane + a * 16 * ldA + step * 32 + 16 * u);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // packed B value index v = u*8 + j*2 + t  ->  register bcur[v >> 2][v & 3]
+            for (int j = 0; j < 4; ++j) {
+                // packed B value index v = u*8 + j*2 + t  ->  register bcur[v >> 2][v & 3]
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int v = u * 8 + j * 2 + t;
-                        const float b = bcur[v >> 2][v & 3];
+                for (int t = 0; t < 2; ++t) {
+                    const int v = u * 8 + j * 2 + t;
+                    const float b = bcur[v >> 2][v & 3];
 #pragma unroll
-                        // weights are the A operand (rows = channels), activations the B operand (columns = pixels): a lane ends
-                        // up with 4 CONSECUTIVE CHANNELS of one pixel -> 16-byte stores, full 128-byte lines per pixel and wave
-                        for (int a = 0; a < RT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, av[a][j], acc[a][t], 0, 0, 0);
-                    }
+                    // weights are the A operand (rows = channels), activations the B operand (columns = pixels): a lane ends
+                    // up with 4 CONSECUTIVE CHANNELS of one pixel -> 16-byte stores, full 128-byte lines per pixel and wave
+                    for (int a = 0; a < RT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, av[a][j], acc[a][t], 0, 0, 0);
                 }
             }
         }
+    };
+    int s0 = 0;
+    for (; s0 + PF <= nsteps; s0 += PF) {
+        one(s0, std::integral_constant<int, 0>{});
+        if (PF > 1) one(s0 + 1, std::integral_constant<int, 1 % PF>{});
+        if (PF > 2) one(s0 + 2, std::integral_constant<int, 2 % PF>{});
+    }
+    if (s0 < nsteps) { one(s0, std::integral_constant<int, 0>{}); ++s0; }
+    if (PF > 2 && s0 < nsteps) { one(s0, std::integral_constant<int, 1 % PF>{}); ++s0; }
+    if (DBG & 32) {
+        f32x4 sink = bx[0][0];
+#pragma unroll
+        for (int a = 0; a < ((DBG & 32) ? PF : 1); ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sink += bx[a][j];
+        if (p.N < 0) *(f32x4*)(p.out) = sink;           // never taken
     }
     // epilogue: D layout row (channel) = (lane>>4)*4 + reg, col (pixel) = lane&15
 #pragma unroll
@@ -1218,17 +1250,18 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
     }
 }
 
-template <int BM, int NW>
+template <int BM, int NW, int DBG = 0>
 static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
-    const size_t lds = (size_t)BM * (p.C + 4) * sizeof(float);
+    size_t lds = (size_t)BM * (p.C + 4) * sizeof(float);
+    if (DBG & 256) lds += (size_t)NW * 4096;
     const int nsplit = (p.cout / 32) / NW;
     static LdsAttrOnce attr;
     if (lds > 48 * 1024) {
-        hipError_t e = attr.ensure((const void*)dwpw_kernel<BM, NW>, 160 * 1024);
+        hipError_t e = attr.ensure((const void*)dwpw_kernel<BM, NW, DBG>, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((dwpw_kernel<BM, NW>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
+    hipLaunchKernelGGL((dwpw_kernel<BM, NW, DBG>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }
 
@@ -1237,9 +1270,7 @@ bool dwpw_supported(int C, int cout) {
 }
 
 hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
-    DwPwParams p = p_in;
-    static const char* dbg = getenv("LWP_DWPW_DEBUG");
-    p.debug = dbg ? atoi(dbg) : 0;
+    const DwPwParams& p = p_in;
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     const int nw = p.cout / 32;
     // rows per workgroup: the largest of 64 / 32 / 16 that still leaves ~2-4 workgroups per CU (measured at batch 1:
@@ -1255,6 +1286,15 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     if (env2 && atoi(env2) < nw && nw % atoi(env2) == 0) nw_wg = atoi(env2);
     if (bm > 64) bm = 64;
     while (bm > 16 && (size_t)bm * (p.C + 4) * sizeof(float) > 150 * 1024) bm >>= 1;
+#ifdef LWP_ABLATION
+    static const char* dbg = getenv("LWP_DWPW_DEBUG");
+    const int d = dbg ? atoi(dbg) : 0;
+#define DP_DBG(BM_, NW_, D_) if (bm == BM_ && nw_wg == NW_ && d == D_) return launch_dwpw_t<BM_, NW_, D_>(p, s);
+#define DP_DBGS(BM_, NW_) DP_DBG(BM_, NW_, 1) DP_DBG(BM_, NW_, 2) DP_DBG(BM_, NW_, 3) DP_DBG(BM_, NW_, 4) DP_DBG(BM_, NW_, 6) DP_DBG(BM_, NW_, 7) DP_DBG(BM_, NW_, 8) DP_DBG(BM_, NW_, 16) DP_DBG(BM_, NW_, 17) DP_DBG(BM_, NW_, 33) DP_DBG(BM_, NW_, 49) DP_DBG(BM_, NW_, 97) DP_DBG(BM_, NW_, 161) DP_DBG(BM_, NW_, 257)
+    DP_DBGS(16, 16) DP_DBGS(16, 8) DP_DBGS(16, 4)
+#undef DP_DBGS
+#undef DP_DBG
+#endif
 #define DP_CASE(BM_, NW_) if (bm == BM_ && nw_wg == NW_) return launch_dwpw_t<BM_, NW_>(p, s);
     DP_CASE(16, 2) DP_CASE(32, 2) DP_CASE(64, 2)
     DP_CASE(16, 4) DP_CASE(32, 4) DP_CASE(64, 4)
