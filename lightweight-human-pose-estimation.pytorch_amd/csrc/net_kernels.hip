@@ -630,8 +630,10 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_wp_kernel(GemmParams
     constexpr int taps = KSZ * KSZ;
     const int nsteps = taps * ksteps_per_tap;
     // B: the weights in fragment order, [step][32-channel tile][s][lane][4] -> one step of this wave = 4 KiB contiguous
-    const float* b_lane = p.wf + ((int64_t)(n0 >> 5) * 4 * 64 + lane) * 4;
-    const int64_t b_step = (int64_t)(p.cout_pad >> 5) * 4 * 64 * 4;
+    // buffer loads (wave-uniform descriptor and step offset, one 32-bit offset register per lane): see gemm_ar_kernel
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wf, 0, 0x7fffffff, 0x00020000);
+    const unsigned b_tile = (unsigned)__builtin_amdgcn_readfirstlane(n0 >> 5) * 4096u;       // bytes
+    const unsigned b_step = (unsigned)(p.cout_pad >> 5) * 4096u;
 
     f32x4 a_reg[4], b_nxt[BK / 8];
     auto load_step = [&](int step) {
@@ -647,9 +649,9 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_wp_kernel(GemmParams
             const float* src = ok ? p.in + a_base[i] + shift : p.zeros;       // out-of-image taps read the zero page
             a_reg[i] = *(const f32x4*)src;
         }
-        const float* bs = b_lane + step * b_step;
+        const unsigned soff = (unsigned)step * b_step + b_tile;
 #pragma unroll
-        for (int s = 0; s < BK / 8; ++s) b_nxt[s] = *(const f32x4*)(bs + s * 256);
+        for (int s = 0; s < BK / 8; ++s) b_nxt[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + s * 1024, soff, 0));
     };
     auto store_step = [&]() {
 #pragma unroll
@@ -847,13 +849,16 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_ar_kernel(GemmParams
     constexpr int taps = KSZ * KSZ;
     const int my_steps = nb * taps;
     // B: fragment order [step = tap * kpt + block][32-channel tile][s][lane][4]
-    const float* b_lane = p.wf + ((int64_t)(n0 >> 5) * 4 * 64 + lane) * 4;
-    const int64_t b_step = (int64_t)(p.cout_pad >> 5) * 4 * 64 * 4;
+    // buffer loads: descriptor + step offset wave-uniform (SGPRs), one 32-bit offset register per lane — a 64-bit per-lane
+    // address (global_load) costs ~3x the issue time while the matrix pipes are busy (measured on the fused dw+pw kernel)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wf, 0, 0x7fffffff, 0x00020000);
+    const unsigned b_tile = (unsigned)__builtin_amdgcn_readfirstlane(n0 >> 5) * 4096u;       // bytes
+    const unsigned b_step = (unsigned)(p.cout_pad >> 5) * 4096u;
     auto load_b = [&](int i, f32x4* dst) {                  // i-th step of this group: block j = i / taps, tap = i % taps
         const int j = i / taps, tap = i - j * taps;
-        const float* bs = b_lane + (int64_t)(tap * kpt + g + j * KS) * b_step;
+        const unsigned soff = (unsigned)(tap * kpt + g + j * KS) * b_step + b_tile;
 #pragma unroll
-        for (int s = 0; s < BK / 8; ++s) dst[s] = *(const f32x4*)(bs + s * 256);
+        for (int s = 0; s < BK / 8; ++s) dst[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + s * 1024, soff, 0));
     };
     constexpr int PF = AR_PF;                               // weight steps in flight per wave (register ring, static indices)
     f32x4 bv[PF][BK / 8];
