@@ -76,14 +76,17 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     // weight stream stay in flight per wave — the bf16 MFMA phase is far too short to hide a 1-step prefetch
     constexpr int PF = 2;
     bf16x8 bw[PF][2];
+    // buffer loads: descriptor and step offset are wave-uniform (SGPRs), a lane supplies one 32-bit offset register — with a
+    // 64-bit per-lane address (global_load) a request costs ~3x the issue time while the matrix pipes are busy
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pw, 0, 0x7fffffff, 0x00020000);
     auto load_b = [&](int step, bf16x8* dst) {
-        const __bf16* src = pw + ((int64_t)(step * nwt + wave) * 2) * 512 + lane * 8;
-        dst[0] = *(const bf16x8*)src;
-        dst[1] = *(const bf16x8*)(src + 512);
+        const unsigned soff = (unsigned)(step * nwt + wave_u) * 2048u;
+        dst[0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16, soff, 0));
+        dst[1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + 1024, soff, 0));
     };
 #pragma unroll
-    for (int j = 0; j < PF - 1; ++j)
-        if (j < nsteps) load_b(j, bw[j]);
+    for (int j = 0; j < PF - 1; ++j) load_b(j < nsteps ? j : nsteps - 1, bw[j]);
 
     // ---- phase 1: one 4-channel chunk per thread (its 9 weight vectors + bias stay in registers), walking groups of
     // PXG consecutive output pixels; inside one image row (stride 1, dilation 1) the group shares a 3 x (PXG+2) input
@@ -203,21 +206,29 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
 #pragma unroll
     for (int a = 0; a < RT; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const __bf16* x_lane = At + i16 * ldA + 8 * q;
-    for (int s0 = 0; s0 < nsteps; s0 += PF) {
+    // one K step; the request for step + PF - 1 is UNCONDITIONAL (past the end: the last step again) and the ring index
+    // static, so that the compiler counts the loads in flight instead of waiting for vmcnt(0)
+    auto one = [&](int step, auto P_) {
+        constexpr int P = decltype(P_)::value;
+        const int nxt = step + PF - 1 < nsteps ? step + PF - 1 : nsteps - 1;
+        if (!(DBG & 2)) load_b(nxt, bw[(P + PF - 1) % PF]);
+        __builtin_amdgcn_sched_barrier(0);           // keep the requests ahead of this step's MFMAs
 #pragma unroll
-        for (int jb = 0; jb < PF; ++jb) {
-            const int step = s0 + jb;
-            if (step >= nsteps) break;
-            if (step + PF - 1 < nsteps && !(DBG & 2)) load_b(step + PF - 1, bw[(jb + PF - 1) % PF]);
-#pragma unroll
-            for (int a = 0; a < RT; ++a) {
-                const bf16x8 xv = *(const bf16x8*)(x_lane + a * 16 * ldA + step * 32);
-                if (DBG & 4) { asm volatile("" ::"v"(xv)); continue; }
-                acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[jb][0], xv, acc[a][0], 0, 0, 0);
-                acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[jb][1], xv, acc[a][1], 0, 0, 0);
-            }
+        for (int a = 0; a < RT; ++a) {
+            const bf16x8 xv = *(const bf16x8*)(x_lane + a * 16 * ldA + step * 32);
+            if (DBG & 4) { asm volatile("" ::"v"(xv)); continue; }
+            acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P][0], xv, acc[a][0], 0, 0, 0);
+            acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P][1], xv, acc[a][1], 0, 0, 0);
         }
+    };
+    int s0 = 0;
+    for (; s0 + PF <= nsteps; s0 += PF) {
+        one(s0, std::integral_constant<int, 0>{});
+        if (PF > 1) one(s0 + 1, std::integral_constant<int, 1 % PF>{});
+        if (PF > 2) one(s0 + 2, std::integral_constant<int, 2 % PF>{});
     }
+    if (s0 < nsteps) { one(s0, std::integral_constant<int, 0>{}); ++s0; }
+    if (PF > 2 && s0 < nsteps) { one(s0, std::integral_constant<int, 1 % PF>{}); ++s0; }
     // epilogue
     __bf16* out = (__bf16*)p.out;
     const __bf16* res = (const __bf16*)p.res;
@@ -359,8 +370,13 @@ __global__ void __launch_bounds__((BM / (32 * RM)) * (BN / (32 * RN)) * 64) gemm
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
 
+    // both operand streams use buffer loads (wave-uniform descriptor + step offset in SGPRs, one 32-bit offset register per
+    // lane): with a 64-bit per-lane address a request costs ~3x the issue time while the matrix pipes are busy, and this kernel
+    // issues one request per 16 MFMA cycles.  Pixels outside the image read offset 2^31 >= num_records -> the hardware returns 0.
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)(M * p.in_ld * 2), 0x00020000);   // host: < 2^31 bytes
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wgt, 0, 0x7fffffff, 0x00020000);
     int a_lds[A_PER], a_y[A_PER], a_x[A_PER];
-    int64_t a_base[A_PER];
+    unsigned a_base[A_PER];
     bool a_ok[A_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
@@ -372,14 +388,14 @@ __global__ void __launch_bounds__((BM / (32 * RM)) * (BN / (32 * RN)) * 64) gemm
         const int64_t mm = a_ok[i] ? m : 0;
         a_x[i] = (int)(mm % p.W);
         a_y[i] = (int)((mm / p.W) % p.H);
-        a_base[i] = mm * p.in_ld + col;
+        a_base[i] = (unsigned)(mm * p.in_ld + col) * 2u;          // bytes
     }
     int b_off[B_PER], b_lds[B_PER];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
         const int ch = tid + i * NT;
         const int row = ch >> 3, col = (ch & 7) * 8;
-        b_off[i] = row * p.cin_pad + col;
+        b_off[i] = (row * p.cin_pad + col) * 2;                    // bytes
         b_lds[i] = row * HLD + col;
     }
     const int ksteps_per_tap = p.cin_pad / HBK;
@@ -391,17 +407,17 @@ __global__ void __launch_bounds__((BM / (32 * RM)) * (BN / (32 * RN)) * 64) gemm
         const int c0 = (step - tap * ksteps_per_tap) * HBK;
         int dy = 0, dx = 0;
         if (p.ks == 3) { dy = (tap / 3 - 1) * p.dil; dx = (tap % 3 - 1) * p.dil; }
-        const int64_t shift = ((int64_t)dy * p.W + dx) * p.in_ld + c0;
+        const int shift = (((dy * p.W + dx) * p.in_ld) + c0) * 2;                    // bytes, may be negative
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
             const bool ok = a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            const __bf16* src = ok ? in + a_base[i] + shift : (const __bf16*)p.zeros;
-            a_reg[i] = *(const bf16x8*)src;
+            const unsigned off = ok ? a_base[i] + (unsigned)shift : 0x80000000u;
+            a_reg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(arsrc, off, 0, 0));
         }
-        const __bf16* wt = wgt + ((int64_t)tap * p.cout_pad + n0) * p.cin_pad + c0;
+        const unsigned woff = (unsigned)__builtin_amdgcn_readfirstlane(((tap * p.cout_pad + n0) * p.cin_pad + c0) * 2);
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) b_reg[i] = *(const bf16x8*)(wt + b_off[i]);
+        for (int i = 0; i < B_PER; ++i) b_reg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], woff, 0));
     };
     auto store_step = [&](int buf) {
         __bf16* a = As + buf * BM * HLD;
@@ -500,6 +516,7 @@ template <int BM, int BN, int RM, int RN>
 static hipError_t launch_gemm_bf16_t(const GemmParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.H * p.W;
     const int64_t tiles = ((M + BM - 1) / BM) * (p.cout_pad / BN);
+    if (M * p.in_ld * 2 >= (1ll << 31)) return hipErrorInvalidValue;        // 32-bit buffer offsets (2 GiB of activations per launch)
     constexpr int NT = (BM / (32 * RM)) * (BN / (32 * RN)) * 64;
     const size_t lds = (size_t)2 * (BM + BN) * HLD * 2;
     static LdsAttrOnce attr;
@@ -576,11 +593,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
     }
     bf16x8 b_reg[BD][B_PER];
     int n0 = 0;                                        // first output channel of the tile whose weights are being streamed
+    // buffer loads: wave-uniform descriptor and tile/tap offset in SGPRs, one 32-bit offset register per lane (a 64-bit per-lane
+    // address costs ~3x the issue time while the matrix pipes are busy)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wgt, 0, 0x7fffffff, 0x00020000);
     auto load_b = [&](int step, bf16x8* dst) {
         const int kb = step / taps, tap = step - kb * taps;
-        const __bf16* wt = wgt + ((int64_t)tap * p.cout_pad + n0) * CIN + kb * HBK;
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((tap * p.cout_pad + n0) * CIN + kb * HBK) * 2);
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) dst[i] = *(const bf16x8*)(wt + b_off[i]);
+        for (int i = 0; i < B_PER; ++i) dst[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i] * 2, soff, 0));
     };
     auto store_b = [&](int buf, const bf16x8* src) {
         __bf16* b = Bs + buf * BN * HLD;
