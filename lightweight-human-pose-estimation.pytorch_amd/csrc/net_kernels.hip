@@ -1059,8 +1059,10 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
 //            never touches LDS: it is packed on the host in fragment order [k-step][wave][4][lane][4 floats], so each
 //            wave streams its own 4 KiB per 32-deep step from L2 with four fully coalesced 1-KiB loads, prefetched
 //            one step ahead in registers.  With 4 waves per SIMD and no barrier the matrix pipes stay fed.
-template <int BM, int NW, int DBG = 0>
+template <int BM, int NW, int DBG = 0, int ACT = -1>
 __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
+    // ACT >= 0: both activations known at compile time (ReLU for every conv_dw block): no chain of scalar branches per vector
+    const int act_dw = ACT >= 0 ? ACT : p.act_dw, act_pw = ACT >= 0 ? ACT : p.act_pw;
     constexpr int NT = NW * 64;
     constexpr int RT = BM / 16;                      // row tiles per wave
     extern __shared__ __attribute__((aligned(16))) float dsm[];
@@ -1144,8 +1146,8 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
                     f32x4 acc = bias;
 #pragma unroll
                     for (int t = 0; t < 9; ++t) acc += win[t / 3][i + t % 3] * wv[t];
-                    acc.x = apply_act(acc.x, p.act_dw); acc.y = apply_act(acc.y, p.act_dw);
-                    acc.z = apply_act(acc.z, p.act_dw); acc.w = apply_act(acc.w, p.act_dw);
+                    acc.x = apply_act(acc.x, act_dw); acc.y = apply_act(acc.y, act_dw);
+                    acc.z = apply_act(acc.z, act_dw); acc.w = apply_act(acc.w, act_dw);
                     *(f32x4*)(At + (row0 + i) * ldA + c) = acc;
                 }
                 continue;
@@ -1170,8 +1172,8 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
                 f32x4 acc = bias;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) acc += x[t] * wv[t];
-                acc.x = apply_act(acc.x, p.act_dw); acc.y = apply_act(acc.y, p.act_dw);
-                acc.z = apply_act(acc.z, p.act_dw); acc.w = apply_act(acc.w, p.act_dw);
+                acc.x = apply_act(acc.x, act_dw); acc.y = apply_act(acc.y, act_dw);
+                acc.z = apply_act(acc.z, act_dw); acc.w = apply_act(acc.w, act_dw);
                 *(f32x4*)(At + (row0 + i) * ldA + c) = acc;
             }
         }
@@ -1246,8 +1248,8 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
             const int64_t m = m0 + a * 16 + r16;
             if (m < M) {
                 f32x4 v = acc[a][t] + bias;
-                v.x = apply_act(v.x, p.act_pw); v.y = apply_act(v.y, p.act_pw);
-                v.z = apply_act(v.z, p.act_pw); v.w = apply_act(v.w, p.act_pw);
+                v.x = apply_act(v.x, act_pw); v.y = apply_act(v.y, act_pw);
+                v.z = apply_act(v.z, act_pw); v.w = apply_act(v.w, act_pw);
                 if (p.res) v += *(const f32x4*)(p.res + m * p.res_ld + n);
                 *(f32x4*)(p.out + m * p.out_ld + n) = v;
             }
@@ -1255,7 +1257,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
     }
 }
 
-template <int BM, int NW, int DBG = 0>
+template <int BM, int NW, int DBG = 0, int ACT = -1>
 static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     size_t lds = (size_t)BM * (p.C + 4) * sizeof(float);
@@ -1263,10 +1265,10 @@ static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
     const int nsplit = (p.cout / 32) / NW;
     static LdsAttrOnce attr;
     if (lds > 48 * 1024) {
-        hipError_t e = attr.ensure((const void*)dwpw_kernel<BM, NW, DBG>, 160 * 1024);
+        hipError_t e = attr.ensure((const void*)dwpw_kernel<BM, NW, DBG, ACT>, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((dwpw_kernel<BM, NW, DBG>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
+    hipLaunchKernelGGL((dwpw_kernel<BM, NW, DBG, ACT>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }
 
@@ -1300,7 +1302,8 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
 #undef DP_DBGS
 #undef DP_DBG
 #endif
-#define DP_CASE(BM_, NW_) if (bm == BM_ && nw_wg == NW_) return launch_dwpw_t<BM_, NW_>(p, s);
+    const bool relu = p.act_dw == ACT_RELU && p.act_pw == ACT_RELU;
+#define DP_CASE(BM_, NW_) if (bm == BM_ && nw_wg == NW_) return relu ? launch_dwpw_t<BM_, NW_, 0, ACT_RELU>(p, s) : launch_dwpw_t<BM_, NW_>(p, s);
     DP_CASE(16, 2) DP_CASE(32, 2) DP_CASE(64, 2)
     DP_CASE(16, 4) DP_CASE(32, 4) DP_CASE(64, 4)
     DP_CASE(16, 8) DP_CASE(32, 8) DP_CASE(64, 8)

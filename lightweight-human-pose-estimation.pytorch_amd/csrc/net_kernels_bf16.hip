@@ -47,8 +47,11 @@ static int device_cu_count() {
 // A lane (i = lane&15, q = lane>>4) reads 8 consecutive k (16 B) at k = 32s + 8q: exactly the operand lane map, for
 // the activation tile (from LDS) and for the fragment-packed weights [k-step][wave][tile][lane][8] (from L2) alike.
 // DBG (compile time; LWP_ABLATION builds only): 1 no depthwise phase, 2 no weight stream, 4 no MFMA, 8 no epilogue
-template <int BM, int NW, int DBG = 0, int SDIL = 1>
+template <int BM, int NW, int DBG = 0, int SDIL = 1, int ACT = -1>
 __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
+    // ACT >= 0: both activations known at compile time (ReLU for every conv_dw block) — with the run-time switch every output
+    // vector walks a chain of scalar branches and the basic-block boundaries keep the loads from overlapping the arithmetic
+    const int act_dw = ACT >= 0 ? ACT : p.act_dw, act_pw = ACT >= 0 ? ACT : p.act_pw;
     constexpr int NT = NW * 64;
     constexpr int RT = BM / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
@@ -101,7 +104,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
         for (int t = 0; t < 9; ++t) wv[t] = *(const f32x4*)(p.dw_w + t * p.C + c);
         const f32x4 bias = *(const f32x4*)(p.dw_w + 9 * p.C + c);
         auto finish = [&](f32x4 a, int row) {
-            const bf16x4 o = {(__bf16)act_f(a.x, p.act_dw), (__bf16)act_f(a.y, p.act_dw), (__bf16)act_f(a.z, p.act_dw), (__bf16)act_f(a.w, p.act_dw)};
+            const bf16x4 o = {(__bf16)act_f(a.x, act_dw), (__bf16)act_f(a.y, act_dw), (__bf16)act_f(a.z, act_dw), (__bf16)act_f(a.w, act_dw)};
             *(bf16x4*)(At + row * ldA + c) = o;
         };
         // dilation 2 (model.7): the 3 x (PXG + 4) window does not fit the 128-VGPR cap of the 16-wave workgroups, so the group
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
         for (int a = 0; a < RT; ++a) {
             const int64_t m = m0 + a * 16 + i16;
             f32x4 v = acc[a][t] + bias;
-            v.x = act_f(v.x, p.act_pw); v.y = act_f(v.y, p.act_pw); v.z = act_f(v.z, p.act_pw); v.w = act_f(v.w, p.act_pw);
+            v.x = act_f(v.x, act_pw); v.y = act_f(v.y, act_pw); v.z = act_f(v.z, act_pw); v.w = act_f(v.w, act_pw);
             if (res && m < M) {                      // residual before the (single) rounding to bf16
                 const bf16x4 r = *(const bf16x4*)(res + m * p.res_ld + n);
                 v.x += (float)r[0]; v.y += (float)r[1]; v.z += (float)r[2]; v.w += (float)r[3];
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     }
 }
 
-template <int BM, int NW, int DBG = 0, int SDIL = 1>
+template <int BM, int NW, int DBG = 0, int SDIL = 1, int ACT = -1>
 static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     size_t lds = (size_t)BM * (p.C + 8) * 2;
@@ -284,10 +287,10 @@ static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     const int nsplit = (p.cout / 32) / NW;
     static LdsAttrOnce attr;
     if (lds > 48 * 1024) {
-        hipError_t e = attr.ensure((const void*)dwpw_bf16_kernel<BM, NW, DBG, SDIL>, 160 * 1024);
+        hipError_t e = attr.ensure((const void*)dwpw_bf16_kernel<BM, NW, DBG, SDIL, ACT>, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((dwpw_bf16_kernel<BM, NW, DBG, SDIL>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
+    hipLaunchKernelGGL((dwpw_bf16_kernel<BM, NW, DBG, SDIL, ACT>), dim3((unsigned)((M + BM - 1) / BM), nsplit), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }
 
@@ -323,10 +326,11 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
 #endif
     // the dilation-2 layer (model.7, 512 -> 512) gets its own instantiation: carrying both shared-window forms in one kernel
     // spills 38 VGPRs at the 128-VGPR cap of the 16-wave workgroups
-#define DPH_DIL2(BM_) if (bm == BM_ && nw == 16 && p.dil == 2 && p.stride == 1) return launch_dwpw_bf16_t<BM_, 16, 0, 2>(p, s);
+    const bool relu = p.act_dw == ACT_RELU && p.act_pw == ACT_RELU;
+#define DPH_DIL2(BM_) if (bm == BM_ && nw == 16 && p.dil == 2 && p.stride == 1) return relu ? launch_dwpw_bf16_t<BM_, 16, 0, 2, ACT_RELU>(p, s) : launch_dwpw_bf16_t<BM_, 16, 0, 2>(p, s);
     DPH_DIL2(16) DPH_DIL2(32) DPH_DIL2(64) DPH_DIL2(128)
 #undef DPH_DIL2
-#define DPH_CASE(BM_, NW_) if (bm == BM_ && nw == NW_) return launch_dwpw_bf16_t<BM_, NW_>(p, s);
+#define DPH_CASE(BM_, NW_) if (bm == BM_ && nw == NW_) return relu ? launch_dwpw_bf16_t<BM_, NW_, 0, 1, ACT_RELU>(p, s) : launch_dwpw_bf16_t<BM_, NW_>(p, s);
     DPH_CASE(16, 2) DPH_CASE(32, 2) DPH_CASE(64, 2)
     DPH_CASE(16, 4) DPH_CASE(32, 4) DPH_CASE(64, 4)
     DPH_CASE(16, 8) DPH_CASE(32, 8) DPH_CASE(64, 8)
