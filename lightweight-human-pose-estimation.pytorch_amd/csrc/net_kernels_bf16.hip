@@ -294,6 +294,9 @@ static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Measured and dropped: persistent workgroups (a tile loop around the body, grid = resident workgroups): 3-10 % faster than the same
+// code launched one workgroup per row block, but the loop keeps more values live across the phases (4-39 spilled VGPRs at the
+// 128-VGPR cap of the 16-wave workgroups) and every layer ended 5-25 % SLOWER than the plain form below.
 // Measured and dropped (round 2, batch 32, 512 -> 512, two-phase kernel 143 us): a K-streamed form — persistent workgroups over
 // 8 x 16 pixel patches, the input window of every 64-channel chunk brought in by LDS-DMA (1.4x instead of 4.5x re-reads),
 // depthwise conv from LDS into a double-buffered [128][64] tile, v_mfma_f32_32x32x16_bf16 with the accumulators kept across
