@@ -91,113 +91,91 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
 #pragma unroll
     for (int j = 0; j < PF - 1; ++j) load_b(j < nsteps ? j : nsteps - 1, bw[j]);
 
-    // ---- phase 1: one 4-channel chunk per thread (its 9 weight vectors + bias stay in registers), walking groups of
-    // PXG consecutive output pixels; inside one image row (stride 1, dilation 1) the group shares a 3 x (PXG+2) input
-    // window — the kernel is bound by the number of vector-memory instructions (TA busy ~ kernel time), not by bytes.
-    constexpr int PXG = 4;
+    // ---- phase 1: a thread owns ONE 8-channel chunk (16-byte loads: the phase is bound by the NUMBER of vector-memory
+    // instructions, so 8-byte loads of 4 channels cost twice as much) and walks groups of PXG consecutive output pixels; inside one
+    // image row (stride 1) the group shares its 3 x (PXG + 2 dil) input window.  Loads are buffer loads: the descriptor is
+    // wave-uniform, a lane supplies one 32-bit byte offset, and a tap outside the image gets offset 2^31 >= num_records, for
+    // which the hardware returns zeros (no zero page, no 64-bit address arithmetic).  The depthwise weights (f32 [9][C] + bias
+    // [C]) live in LDS behind the tiles: 80 registers per thread otherwise.
+    constexpr int PXG = 2;                           // a 3 x 4 window of 16-byte vectors: fits the 128-VGPR cap of the 16-wave workgroups
     static_assert(BM % PXG == 0, "row block must hold whole pixel groups");
-    const int cg = p.C >> 2;
+    constexpr int WC_ = NW * 32;
+    const int wd_off = ((BM * (p.C > WC_ ? p.C + 8 : WC_ + 8) * 2) + 15) & ~15;
+    float* Wd = (float*)(dsm_raw + wd_off);          // [10][C]
+    for (int i = tid * 4; i < 10 * p.C; i += NT * 4) *(f32x4*)(Wd + i) = *(const f32x4*)(p.dw_w + i);
+    __syncthreads();
+    const int cg = p.C >> 3;
     if (!(DBG & 1)) {
-        const int c = (tid % cg) * 4;
-        f32x4 wv[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wv[t] = *(const f32x4*)(p.dw_w + t * p.C + c);
-        const f32x4 bias = *(const f32x4*)(p.dw_w + 9 * p.C + c);
-        auto finish = [&](f32x4 a, int row) {
-            const bf16x4 o = {(__bf16)act_f(a.x, act_dw), (__bf16)act_f(a.y, act_dw), (__bf16)act_f(a.z, act_dw), (__bf16)act_f(a.w, act_dw)};
-            *(bf16x4*)(At + row * ldA + c) = o;
+        const int c = (tid % cg) * 8;
+        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 2), 0x00020000);
+        const int pix_b = p.in_ld * 2, row_b = p.Wi * pix_b;       // bytes per input pixel / input row
+        auto ldw = [&](unsigned off) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0)); };
+        struct f32x8 { f32x4 lo, hi; };
+        auto wtap = [&](int t) { return f32x8{*(const f32x4*)(Wd + t * p.C + c), *(const f32x4*)(Wd + t * p.C + c + 4)}; };
+        auto fma8 = [&](f32x8& a, const bf16x8& x, const f32x8& w) {
+            const f32x4 xl = {(float)x[0], (float)x[1], (float)x[2], (float)x[3]}, xh = {(float)x[4], (float)x[5], (float)x[6], (float)x[7]};
+            a.lo += xl * w.lo; a.hi += xh * w.hi;
         };
-        // dilation 2 (model.7): the 3 x (PXG + 4) window does not fit the 128-VGPR cap of the 16-wave workgroups, so the group
-        // walks it one input row at a time — PXG + 2 dil loads per row added into the PXG accumulators before the next row is
-        // touched (6 loads per output pixel instead of 9, one row of vectors live). Same summation order as the general path:
-        // bias, then the nine taps row-major. (The same row-wise walk with 8-pixel groups at dilation 1 was measured 40-90 %
-        // SLOWER than the whole-window code below: the accumulator array defeats the load/FMA overlap the compiler finds there.)
-        auto shared_rows = [&](auto DIL_, const __bf16* base, int yo, int xo, int row0) {
-            constexpr int DIL = decltype(DIL_)::value;
-            constexpr int NV = PXG + 2 * DIL;
-            f32x4 a[PXG];
-#pragma unroll
-            for (int i = 0; i < PXG; ++i) a[i] = bias;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = yo + (ky - 1) * DIL;
-                const bool rok = yy >= 0 && yy < p.Hi;
-                bf16x4 rw[NV];
-#pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    const int xx = xo + j - DIL;
-                    const __bf16* src = (rok && xx >= 0 && xx < p.Wi) ? base + ((int64_t)(ky - 1) * DIL * p.Wi + (j - DIL)) * p.in_ld : (const __bf16*)p.zeros;
-                    rw[j] = *(const bf16x4*)src;
-                }
-#pragma unroll
-                for (int i = 0; i < PXG; ++i)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const bf16x4 w4 = rw[i + kx * DIL];
-                        const f32x4 v = {(float)w4[0], (float)w4[1], (float)w4[2], (float)w4[3]};
-                        a[i] += v * wv[ky * 3 + kx];
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < PXG; ++i) finish(a[i], row0 + i);
+        auto finish = [&](const f32x8& a, int row) {
+            const bf16x8 o = {(__bf16)act_f(a.lo.x, act_dw), (__bf16)act_f(a.lo.y, act_dw), (__bf16)act_f(a.lo.z, act_dw), (__bf16)act_f(a.lo.w, act_dw),
+                              (__bf16)act_f(a.hi.x, act_dw), (__bf16)act_f(a.hi.y, act_dw), (__bf16)act_f(a.hi.z, act_dw), (__bf16)act_f(a.hi.w, act_dw)};
+            *(bf16x8*)(At + row * ldA + c) = o;
         };
         for (int grp = tid / cg; grp < BM / PXG; grp += NT / cg) {
             const int row0 = grp * PXG;
             const int64_t m = m0 + row0;
             const int64_t mm = m < M ? m : 0;
             const int xo = (int)(mm % p.Wo), yo = (int)((mm / p.Wo) % p.Ho);
-            const int64_t img = mm / ((int64_t)p.Wo * p.Ho);
+            const int img = (int)(mm / ((int64_t)p.Wo * p.Ho));
             if (p.stride == 1 && m + PXG <= M && xo + PXG <= p.Wo && p.dil == SDIL) {
-                const __bf16* base = in + ((img * p.Hi + yo) * p.Wi + xo) * p.in_ld + c;
-                if constexpr (SDIL == 2) { shared_rows(std::integral_constant<int, 2>{}, base, yo, xo, row0); continue; }
-                bf16x4 win[3][PXG + 2];                 // dilation 1: the whole 3 x (PXG + 2) window fits the register budget
+                constexpr int NV = PXG + 2 * SDIL;
+                const int base = ((img * p.Hi + yo) * p.Wi + xo) * pix_b + c * 2;
+                f32x8 a[PXG];
+                const f32x8 bias = wtap(9);
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = yo + ky - 1;
-                    const bool rok = yy >= 0 && yy < p.Hi;
+                for (int i = 0; i < PXG; ++i) a[i] = bias;
+                {
+                    bf16x8 win[3][NV];                  // the whole window in flight at once (18 loads at dilation 1), then the tap-vector FMAs
 #pragma unroll
-                    for (int j = 0; j < PXG + 2; ++j) {
-                        const int xx = xo + j - 1;
-                        const __bf16* src = (rok && xx >= 0 && xx < p.Wi) ? base + ((int64_t)(ky - 1) * p.Wi + (j - 1)) * p.in_ld : (const __bf16*)p.zeros;
-                        win[ky][j] = *(const bf16x4*)src;
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int yy = yo + (ky - 1) * SDIL;
+                        const bool rok = yy >= 0 && yy < p.Hi;
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) {
+                            const int xx = xo + j - SDIL;
+                            win[ky][j] = ldw((rok && xx >= 0 && xx < p.Wi) ? (unsigned)(base + (ky - 1) * SDIL * row_b + (j - SDIL) * pix_b) : 0x80000000u);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {       // tap-major: one weight vector live at a time; per pixel the order is bias, taps 0..8
+                        const f32x8 w = wtap(t);
+#pragma unroll
+                        for (int i = 0; i < PXG; ++i) fma8(a[i], win[t / 3][i + (t % 3) * SDIL], w);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < PXG; ++i) {
-                    f32x4 a = bias;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const bf16x4 w4 = win[t / 3][i + t % 3];
-                        const f32x4 v = {(float)w4[0], (float)w4[1], (float)w4[2], (float)w4[3]};
-                        a += v * wv[t];
-                    }
-                    finish(a, row0 + i);
-                }
+                for (int i = 0; i < PXG; ++i) finish(a[i], row0 + i);
                 continue;
             }
 #pragma unroll 1
-            for (int i = 0; i < PXG; ++i) {           // general path: borders of the row block, stride 2, dilation 2
+            for (int i = 0; i < PXG; ++i) {           // general path: groups that cross an image row or the end of the tensor, stride 2
                 const int64_t mi = m0 + row0 + i;
                 const bool ok = mi < M;
                 const int64_t mq = ok ? mi : 0;
                 const int xi = (int)(mq % p.Wo), yi = (int)((mq / p.Wo) % p.Ho);
-                const int64_t im = mq / ((int64_t)p.Wo * p.Ho);
+                const int im = (int)(mq / ((int64_t)p.Wo * p.Ho));
                 const int yc = yi * p.stride, xc = xi * p.stride;
-                const __bf16* base = in + ((im * p.Hi + yc) * p.Wi + xc) * p.in_ld + c;
-                bf16x4 x[9];
+                const int base = ((im * p.Hi + yc) * p.Wi + xc) * pix_b + c * 2;
+                bf16x8 x[9];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
                     const bool inb = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
-                    const __bf16* src = inb ? base + ((int64_t)dy * p.Wi + dx) * p.in_ld : (const __bf16*)p.zeros;
-                    x[t] = *(const bf16x4*)src;
+                    x[t] = ldw(inb ? (unsigned)(base + dy * row_b + dx * pix_b) : 0x80000000u);
                 }
-                f32x4 a = bias;
+                f32x8 a = wtap(9);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const f32x4 v = {(float)x[t][0], (float)x[t][1], (float)x[t][2], (float)x[t][3]};
-                    a += v * wv[t];
-                }
+                for (int t = 0; t < 9; ++t) fma8(a, x[t], wtap(t));
                 finish(a, row0 + i);
             }
         }
@@ -283,7 +261,9 @@ static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     size_t lds = (size_t)BM * (p.C + 8) * 2;
     const size_t lds_out = (size_t)BM * (NW * 32 + 8) * 2;          // the staged output tile re-uses the space
     if (lds_out > lds) lds = lds_out;
+    lds = ((lds + 15) & ~(size_t)15) + (size_t)10 * p.C * sizeof(float);   // + the depthwise weights and bias
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 2 >= (1ll << 31) || (p.C & 7)) return hipErrorInvalidValue;   // 32-bit buffer offsets, 8-channel lanes
     const int nsplit = (p.cout / 32) / NW;
     static LdsAttrOnce attr;
     if (lds > 48 * 1024) {
@@ -315,7 +295,7 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
     if (M / 64 >= 1024 && nw >= 8) bm = 128;         // >= 256 output channels: halve the per-workgroup weight stream (measured 3-8 %)
     static const char* env = getenv("LWP_DWPW_BM");
     if (env) bm = atoi(env);
-    while (bm > 16 && (size_t)bm * ((p.C > p.cout ? p.C : p.cout) + 8) * 2 > 150 * 1024) bm >>= 1;
+    while (bm > 16 && (size_t)bm * ((p.C > p.cout ? p.C : p.cout) + 8) * 2 + (size_t)40 * p.C + 16 > 160 * 1024) bm >>= 1;
     if (bm == 128 && nw < 4) bm = 64;
     // every thread must own a whole 8-channel chunk column: NW*64 threads must be a multiple of C/8 (always true here)
 #ifdef LWP_ABLATION
@@ -323,7 +303,7 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
     const int d = dbg ? atoi(dbg) : 0;
 #define DPH_DBG(BM_, NW_, D_) if (bm == BM_ && nw == NW_ && d == D_) return launch_dwpw_bf16_t<BM_, NW_, D_>(p, s);
 #define DPH_DBGS(BM_, NW_) DPH_DBG(BM_, NW_, 1) DPH_DBG(BM_, NW_, 2) DPH_DBG(BM_, NW_, 4) DPH_DBG(BM_, NW_, 6) DPH_DBG(BM_, NW_, 7) DPH_DBG(BM_, NW_, 8) DPH_DBG(BM_, NW_, 14) DPH_DBG(BM_, NW_, 15)
-    DPH_DBGS(128, 16) DPH_DBGS(64, 2) DPH_DBGS(64, 4)
+    DPH_DBGS(128, 16) DPH_DBGS(64, 16) DPH_DBGS(32, 16) DPH_DBGS(64, 2) DPH_DBGS(64, 4)
 #undef DPH_DBGS
 #undef DPH_DBG
 #endif
@@ -333,7 +313,8 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
 #define DPH_DIL2(BM_) if (bm == BM_ && nw == 16 && p.dil == 2 && p.stride == 1) return relu ? launch_dwpw_bf16_t<BM_, 16, 0, 2, ACT_RELU>(p, s) : launch_dwpw_bf16_t<BM_, 16, 0, 2>(p, s);
     DPH_DIL2(16) DPH_DIL2(32) DPH_DIL2(64) DPH_DIL2(128)
 #undef DPH_DIL2
-#define DPH_CASE(BM_, NW_) if (bm == BM_ && nw == NW_) return relu ? launch_dwpw_bf16_t<BM_, NW_, 0, 1, ACT_RELU>(p, s) : launch_dwpw_bf16_t<BM_, NW_>(p, s);
+    const bool elu = p.act_dw == ACT_ELU && p.act_pw == ACT_ELU;       // the conv_dw_no_bn blocks of the cpm trunk
+#define DPH_CASE(BM_, NW_) if (bm == BM_ && nw == NW_) return relu ? launch_dwpw_bf16_t<BM_, NW_, 0, 1, ACT_RELU>(p, s) : elu ? launch_dwpw_bf16_t<BM_, NW_, 0, 1, ACT_ELU>(p, s) : launch_dwpw_bf16_t<BM_, NW_>(p, s);
     DPH_CASE(16, 2) DPH_CASE(32, 2) DPH_CASE(64, 2)
     DPH_CASE(16, 4) DPH_CASE(32, 4) DPH_CASE(64, 4)
     DPH_CASE(16, 8) DPH_CASE(32, 8) DPH_CASE(64, 8)
