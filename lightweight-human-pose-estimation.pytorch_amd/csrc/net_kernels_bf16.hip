@@ -448,16 +448,25 @@ __global__ void __launch_bounds__((BM / (32 * RM)) * (BN / (32 * RN)) * 64) gemm
         __syncthreads();
     }
 
-    // epilogue: D row = channel (e&3) + 8*(e>>2) + 4*h of the 32-channel tile, col = pixel i32
+    // epilogue: D row = channel (e&3) + 8*(e>>2) + 4*h of the 32-channel tile, col = pixel i32.  The accumulator layout gives a lane
+    // 8 bytes of ONE pixel row and the 32 lanes of a half-wave 32 different rows: written out directly that is 64 partial cache
+    // lines per store instruction (heads.0 at batch 32: 140 us for 247 MB).  The tile therefore goes through the (now free) LDS
+    // tiles: bias + activation (+ residual, f32) in registers, bf16 into [BM][BN + 8], then 16 bytes per lane on consecutive
+    // addresses — whole pixel rows of the workgroup's BN channels.  The NCHW stage outputs are pixel-major per channel already.
     __bf16* out = (__bf16*)p.out;
     const __bf16* res = (const __bf16*)p.res;
     const int64_t HW = (int64_t)p.H * p.W;
-    const bool vec_ok = ((p.out_ld & 3) == 0) && ((((uintptr_t)out) & 7) == 0) && (!res || (((p.res_ld & 3) == 0) && ((((uintptr_t)res) & 7) == 0)));
+    constexpr int OLD_ = BN + 8;
+    static_assert((size_t)BM * OLD_ * 2 <= (size_t)2 * (BM + BN) * HLD * 2, "the staged output tile must fit the operand tiles");
+    __bf16* Ot = (__bf16*)hsm_raw;                     // [BM][OLD_] (the last K step ended with a barrier: the tiles are free)
+    const bool res_vec = res && ((p.res_ld & 3) == 0) && ((((uintptr_t)res) & 7) == 0);
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
-        const int64_t m = m0 + (wm * RM + i) * 32 + i32;
-        if (m >= M) continue;
-        const int64_t img = m / HW, pix = m - img * HW;
+        const int lrow = (wm * RM + i) * 32 + i32;
+        const int64_t m = m0 + lrow;
+        const bool mok = m < M;
+        const int64_t mc = mok ? m : 0;
+        const int64_t img = mc / HW, pix = mc - img * HW;
         const int c0 = p.out_split > 0 ? p.out_split : p.cout;
         auto store_nchw = [&](int ch, float val) {       // stage outputs (NCHW); merged heads split at out_split
             if (ch < c0) { if (p.out_nchw) p.out_nchw[(img * c0 + ch) * HW + pix] = val; }
@@ -467,35 +476,43 @@ __global__ void __launch_bounds__((BM / (32 * RM)) * (BN / (32 * RN)) * 64) gemm
         for (int j = 0; j < RN; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + (wn * RN + j) * 32 + 8 * g + 4 * h;
-                if (n >= p.cout) continue;
+                const int lcol = (wn * RN + j) * 32 + 8 * g + 4 * h;
+                const int n = n0 + lcol;
                 f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 const f32x4 bias = *(const f32x4*)(p.bias + n);       // bias is padded to cout_pad
                 v += bias;
                 v.x = act_f(v.x, p.act); v.y = act_f(v.y, p.act); v.z = act_f(v.z, p.act); v.w = act_f(v.w, p.act);
-                if (vec_ok && n + 3 < p.cout) {
-                    if (res) {
+                if (res && mok) {                                     // residual before the (single) rounding to bf16
+                    if (res_vec && n + 3 < p.cout) {
                         const bf16x4 r = *(const bf16x4*)(res + m * p.res_ld + n);
                         v.x += (float)r[0]; v.y += (float)r[1]; v.z += (float)r[2]; v.w += (float)r[3];
-                    }
-                    bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-                    *(bf16x4*)(out + m * p.out_ld + n) = o;
-                    if (p.out_nchw || p.out_nchw2) {
+                    } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) store_nchw(n + e, v[e]);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e < p.cout) {
-                            float u = v[e];
-                            if (res) u += (float)res[m * p.res_ld + n + e];
-                            out[m * p.out_ld + n + e] = (__bf16)u;
-                            if (p.out_nchw || p.out_nchw2) store_nchw(n + e, u);
-                        }
+                        for (int e = 0; e < 4; ++e) if (n + e < p.cout) v[e] += (float)res[m * p.res_ld + n + e];
                     }
                 }
+                if ((p.out_nchw || p.out_nchw2) && mok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.cout) store_nchw(n + e, v[e]);
+                }
+                const bf16x4 o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                *(bf16x4*)(Ot + lrow * OLD_ + lcol) = o;
             }
+        }
+    }
+    __syncthreads();
+    const bool out_vec = ((p.out_ld & 7) == 0) && ((((uintptr_t)out) & 15) == 0);
+    constexpr int CPR = BN / 8;                        // 16-byte chunks per pixel row
+    for (int ch = tid; ch < BM * CPR; ch += NT) {
+        const int row = ch / CPR, col = (ch - row * CPR) * 8;
+        const int64_t m = m0 + row;
+        const int n = n0 + col;
+        if (m >= M || n >= p.cout) continue;
+        const bf16x8 o = *(const bf16x8*)(Ot + row * OLD_ + col);
+        if (out_vec && n + 7 < p.cout) *(bf16x8*)(out + m * p.out_ld + n) = o;
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (n + e < p.cout) out[m * p.out_ld + n + e] = o[e];
         }
     }
 }
