@@ -18,6 +18,7 @@ struct lwp_context {
     hipStream_t stream = nullptr;
     int dtype = LWP_F32;
     Graph g;
+    bool fuse_heads = true;                // bf16: head pairs as one kernel (LWP_FUSE_HEADS=0 at lwp_create: two GEMMs)
     float* d_blob = nullptr;
     float* d_zeros = nullptr;
     bool weights_loaded = false;
@@ -138,6 +139,8 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
         const char* fe = getenv("LWP_FUSE_DWPW");   // "0" keeps depthwise and pointwise as separate launches (A/B, tests)
         const char* me = getenv("LWP_MERGE_HEADS");   // "0": separate heat / PAF head GEMMs (A/B)
         h->g = build_graph(nref, C, NH, NP, !(fe && fe[0] == '0'), dtype, !(me && me[0] == '0'));
+        const char* he = getenv("LWP_FUSE_HEADS");
+        h->fuse_heads = !(he && he[0] == '0');
     }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
@@ -415,13 +418,50 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
     return LWP_OK;
 }
 
+// bf16: a stage's merged head pair (".heads.0" 1x1 C -> hidden + ReLU, ".heads.1" 1x1 hidden -> NH + NP) runs as one kernel
+// that keeps the hidden tensor on the CU.  LWP_FUSE_HEADS=0 launches the two GEMMs (A/B, tests).
+static bool heads_pair_fusable(lwp_context* h, size_t i) {
+    if (!h->fuse_heads) return false;
+    const std::vector<Layer>& ls = h->g.layers;
+    if (h->dtype != LWP_BF16 || i + 1 >= ls.size()) return false;
+    const Layer& a = ls[i];
+    const Layer& b = ls[i + 1];
+    auto ends_with = [](const std::string& s, const char* suf) { const size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; };
+    if (!ends_with(a.name, ".heads.0") || !ends_with(b.name, ".heads.1")) return false;
+    if (a.kind != L_GEMM || b.kind != L_GEMM || a.ks != 1 || b.ks != 1 || a.act != ACT_RELU || b.act != ACT_NONE) return false;
+    if (a.res.buf >= 0 || b.res.buf >= 0 || a.out_index >= 0) return false;
+    if (b.src.buf != a.dst.buf || b.src.coff != a.dst.coff || b.cin_pad != a.cout_pad || a.cout != a.cout_pad) return false;
+    return heads_bf16_supported(a.cin_pad, a.cout_pad, b.cout_pad);
+}
+
+static int enqueue_heads_pair(lwp_context* h, const Layer& a, const Layer& b, int N, int H, int W, float* const* d_outs_nchw) {
+    int dh, dw;
+    level_dims(H, W, h->g.bufs[b.dst.buf].level, &dh, &dw);
+    HeadsParams p;
+    p.in = buf_at(h, a.src); p.in_ld = a.src.ld;
+    p.w0 = h->d_blob + a.w_off; p.b0 = h->d_blob + a.b_off;
+    p.w1 = h->d_blob + b.w_off; p.b1 = h->d_blob + b.b_off;
+    p.out = buf_at(h, b.dst); p.out_ld = b.dst.ld;
+    p.out_nchw = (b.out_index >= 0 && d_outs_nchw) ? d_outs_nchw[b.out_index] : nullptr;
+    p.out_nchw2 = (b.out_index2 >= 0 && d_outs_nchw) ? d_outs_nchw[b.out_index2] : nullptr;
+    p.out_split = b.out_split;
+    p.N = N; p.H = dh; p.W = dw; p.hidden = a.cout_pad; p.cout = b.cout;
+    LAUNCH(h, KC_PW, launch_heads_bf16(p, h->stream));
+    return LWP_OK;
+}
+
 // enqueue every layer on the handle's stream.  d_outs_nchw: 2*(1+nref) device pointers or null.
 static int enqueue_forward(lwp_context* h, const float* d_in, int N, int H, int W, float* const* d_outs_nchw,
                            int max_layers = 1 << 30) {
-    int li = 0;
-    for (const Layer& l : h->g.layers) {
-        if (li++ >= max_layers) break;
-        int rc = enqueue_layer(h, l, d_in, N, H, W, d_outs_nchw);
+    const std::vector<Layer>& ls = h->g.layers;
+    for (size_t i = 0; i < ls.size() && (int)i < max_layers; ++i) {
+        if ((int)i + 1 < max_layers && heads_pair_fusable(h, i)) {
+            int rc = enqueue_heads_pair(h, ls[i], ls[i + 1], N, H, W, d_outs_nchw);
+            if (rc) return rc;
+            ++i;
+            continue;
+        }
+        int rc = enqueue_layer(h, ls[i], d_in, N, H, W, d_outs_nchw);
         if (rc) return rc;
     }
     return LWP_OK;
@@ -1102,12 +1142,16 @@ extern "C" int lwp_debug_time_layer(lwp_handle h, int idx, int N, int H, int W, 
     rc = ensure_dev(h, &h->d_in, &h->d_in_bytes, (size_t)N * 3 * H * W * sizeof(float));
     if (rc) return rc;
     const Layer& l = h->g.layers[idx];
+    // a fused head pair is timed at its first layer; its second layer has no launch of its own
+    const bool pair = heads_pair_fusable(h, (size_t)idx);
+    if (idx > 0 && heads_pair_fusable(h, (size_t)idx - 1)) { *ms_avg = 0.f; return LWP_OK; }
+    auto one = [&]() { return pair ? enqueue_heads_pair(h, l, h->g.layers[idx + 1], N, H, W, nullptr) : enqueue_layer(h, l, h->d_in, N, H, W, nullptr); };
     hipEvent_t e0, e1;
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) { rc = enqueue_layer(h, l, h->d_in, N, H, W, nullptr); if (rc) return rc; }
+    for (int i = 0; i < 3; ++i) { rc = one(); if (rc) return rc; }
     HIP_TRY(h, hipEventRecord(e0, h->stream));
-    for (int i = 0; i < iters; ++i) { rc = enqueue_layer(h, l, h->d_in, N, H, W, nullptr); if (rc) return rc; }
+    for (int i = 0; i < iters; ++i) { rc = one(); if (rc) return rc; }
     HIP_TRY(h, hipEventRecord(e1, h->stream));
     HIP_TRY(h, hipEventSynchronize(e1));
     float ms = 0.f;

@@ -128,6 +128,18 @@ hipError_t launch_dwpw(const DwPwParams& p, hipStream_t s);
 hipError_t launch_stem_bf16(const StemParams& p, hipStream_t s);
 hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s);
 hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s);
+// a stage's head pair (with_mobilenet.py:32-45, 1x1 C -> hidden, ReLU, 1x1 hidden -> NH + NP) as ONE kernel: the hidden tensor
+// (247 MB at batch 32 for the initial stage) never leaves the CU.  Weights in the plain [cout_pad][cin_pad] bf16 layout.
+struct HeadsParams {
+    const void* in; int in_ld;           // [M][128] bf16
+    const void* w0; const float* b0;     // [hidden][128] bf16, [hidden]
+    const void* w1; const float* b1;     // [64][hidden] bf16 (rows >= cout are zero), [64]
+    void* out; int out_ld;               // bf16 NHWC window (the concat buffer at the heat/PAF channels)
+    float* out_nchw; float* out_nchw2;   // may be null: stage outputs, split at out_split
+    int out_split, N, H, W, hidden, cout;
+};
+bool heads_bf16_supported(int cin_pad, int hidden, int cout_pad);
+hipError_t launch_heads_bf16(const HeadsParams& p, hipStream_t s);
 hipError_t launch_nchw_from_nhwc_bf16(const void* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, hipStream_t s);
 hipError_t launch_dw(const DwParams& p, hipStream_t s);

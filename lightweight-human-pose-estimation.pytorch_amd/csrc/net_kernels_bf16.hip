@@ -533,6 +533,163 @@ static hipError_t launch_gemm_bf16_t(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------- stage heads, both 1x1 convs in one kernel
+// out[m][0..NH+NP) = W1 . relu(W0 . x[m] + b0) + b1 with the hidden vector (1024 wide in the initial stage: 247 MB per tensor at
+// batch 32, written by one GEMM and read back by the next) kept on the CU.  Workgroup = 4 waves = 128 pixels, wave = 32 pixels:
+//   - the wave's activations are loaded ONCE, straight into MFMA operand registers (8 k-slices of v_mfma_f32_32x32x16_bf16);
+//   - the hidden dimension is walked in chunks of 64: W0 chunk [64][128] and W1 chunk [64 out][64] staged in LDS (double-buffered,
+//     requested a chunk ahead, one barrier per chunk);
+//   - GEMM 1 (16 MFMAs) leaves D[hidden channel][pixel] in the accumulators: lane (pixel i, half h) holds channels
+//     32 j + 8 (e >> 2) + 4 h + (e & 3), e = 0..15.  After bias + ReLU those 16 values ARE the two B-operand k-slices of GEMM 2
+//     if its k-slot (s, h, r) is read as hidden 32 j + 16 s + 8 (r >> 2) + 4 h + (r & 3): a permutation of the summation index,
+//     applied to the W1 fragment instead (two ds_read_b64 at columns 16 s + 4 h and 16 s + 8 + 4 h) — the hidden tile never
+//     touches LDS or another lane;
+//   - GEMM 2 (8 MFMAs per chunk) accumulates the 64 (57 used) output channels of the wave's 32 pixels over all chunks.
+constexpr int HD_BM = 128, HD_CH = 64, HD_K = 128;
+constexpr int HD_W0LD = HD_K + 8, HD_W1LD = HD_CH + 8;
+
+__global__ void __launch_bounds__(256) heads_bf16_kernel(HeadsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hd_raw[];
+    __bf16* W0s = (__bf16*)hd_raw;                                   // [2][64][HD_W0LD]
+    __bf16* W1s = W0s + 2 * HD_CH * HD_W0LD;                         // [2][64][HD_W1LD]
+    float* B0s = (float*)(W1s + 2 * 64 * HD_W1LD);                   // [hidden]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int M = p.N * p.H * p.W;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    }
+    const int m = bid * HD_BM + wave * 32 + i32;
+    const bool mok = m < M;
+    const int nch = p.hidden / HD_CH;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((int64_t)M * p.in_ld * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w0r = __builtin_amdgcn_make_buffer_rsrc((void*)p.w0, 0, p.hidden * HD_K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, 64 * p.hidden * 2, 0x00020000);
+
+    // weight staging: W0 chunk = 64 rows x 256 B (4 x 16 B per thread), W1 chunk = 64 rows x 128 B (2 x 16 B per thread)
+    bf16x8 st0[4], st1[2];
+    auto request = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ch = tid + u * 256, row = ch >> 4, col = (ch & 15) * 8;
+            st0[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w0r, (row * HD_K + col) * 2, c * (HD_CH * HD_K * 2), 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ch = tid + u * 256, row = ch >> 3, col = (ch & 7) * 8;
+            st1[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w1r, (row * p.hidden + col) * 2, c * (HD_CH * 2), 0));
+        }
+    };
+    auto land = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ch = tid + u * 256, row = ch >> 4, col = (ch & 15) * 8;
+            *(bf16x8*)(W0s + (buf * HD_CH + row) * HD_W0LD + col) = st0[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ch = tid + u * 256, row = ch >> 3, col = (ch & 7) * 8;
+            *(bf16x8*)(W1s + (buf * 64 + row) * HD_W1LD + col) = st1[u];
+        }
+    };
+    request(0);
+    // the wave's activations: k-slice s of pixel m = x[m][16 s + 8 h .. + 7]
+    bf16x8 xf[HD_K / 16];
+#pragma unroll
+    for (int s = 0; s < HD_K / 16; ++s)
+        xf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, mok ? (unsigned)((m * p.in_ld + 16 * s + 8 * h) * 2) : 0x80000000u, 0, 0));
+    for (int i = tid * 4; i < p.hidden; i += 256 * 4) *(f32x4*)(B0s + i) = *(const f32x4*)(p.b0 + i);
+    land(0);
+    __syncthreads();
+
+    f32x16 acc2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[t][e] = 0.f;
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        request(c + 1 < nch ? c + 1 : c);                            // unconditional (the last chunk again): exact vmcnt counting
+        __builtin_amdgcn_sched_barrier(0);                           // keep the requests ahead of the chunk's MFMAs
+        const __bf16* w0 = W0s + (buf * HD_CH + i32) * HD_W0LD + 8 * h;
+        const __bf16* w1 = W1s + (buf * 64 + i32) * HD_W1LD + 4 * h;
+        bf16x8 hf[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x16 acc1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < HD_K / 16; ++s) {
+                const bf16x8 wv = *(const bf16x8*)(w0 + j * 32 * HD_W0LD + 16 * s);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xf[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *(const f32x4*)(B0s + c * HD_CH + j * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hf[j][g >> 1][(g & 1) * 4 + r] = (__bf16)fmaxf(acc1[4 * g + r] + b[r], 0.f);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const __bf16* src = w1 + t * 32 * HD_W1LD + j * 32 + 16 * s;
+                    const bf16x4 lo = *(const bf16x4*)src, hi = *(const bf16x4*)(src + 8);
+                    const bf16x8 wv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, hf[j][s], acc2[t], 0, 0, 0);
+                }
+        if (c + 1 < nch) land(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane (pixel i32, half h) holds output channels 32 t + 8 g + 4 h + r
+    if (!mok) return;
+    __bf16* out = (__bf16*)p.out;
+    const int HW = p.H * p.W;
+    const int img = m / HW, pix = m - img * HW;
+    const int c0 = p.out_split > 0 ? p.out_split : p.cout;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = 32 * t + 8 * g + 4 * h;
+            const f32x4 b = *(const f32x4*)(p.b1 + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ch = n + r;
+                if (ch >= p.cout) continue;
+                const float v = acc2[t][4 * g + r] + b[r];
+                out[(int64_t)m * p.out_ld + ch] = (__bf16)v;
+                if (ch < c0) { if (p.out_nchw) p.out_nchw[((int64_t)img * c0 + ch) * HW + pix] = v; }
+                else if (p.out_nchw2) p.out_nchw2[((int64_t)img * (p.cout - c0) + (ch - c0)) * HW + pix] = v;
+            }
+        }
+}
+
+bool heads_bf16_supported(int cin_pad, int hidden, int cout_pad) {
+    return cin_pad == HD_K && hidden % HD_CH == 0 && hidden >= HD_CH && hidden <= 4096 && cout_pad == 64;
+}
+
+hipError_t launch_heads_bf16(const HeadsParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    if (M >= (1ll << 31) - HD_BM || M * p.in_ld * 2 >= (1ll << 31) || (p.in_ld & 7)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(2 * HD_CH * HD_W0LD + 2 * 64 * HD_W1LD) * 2 + (size_t)p.hidden * sizeof(float);
+    static LdsAttrOnce attr;
+    if (lds > 48 * 1024) {
+        hipError_t e = attr.ensure((const void*)heads_bf16_kernel, 96 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(heads_bf16_kernel, dim3((unsigned)((M + HD_BM - 1) / HD_BM)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------- implicit GEMM, activation window resident
 // Dense 3x3 convs with 128 input channels at large M (batch 32: M = 120704 pixels, N = 128, K = 9 x 128).
 // The nine A tiles of a 3x3 conv are ONE pixel window at nine offsets: with pixels flat over (n, y, x) the window of the tile

@@ -877,3 +877,32 @@ def test_bf16_window_resident_gemm_forced_at_small_ragged_sizes(monkeypatch):
         sc = max(1.0, float(r.abs().max()))
         assert np.abs(f - r.numpy()).max() <= BF16_TOL * sc and np.abs(f - r.numpy()).mean() <= BF16_MEAN * sc
         assert np.abs(f - q).max() <= BF16_TOL * sc            # same bf16 inputs, different summation order only
+
+
+@pytest.mark.gpu
+def test_bf16_fused_head_pair_matches_the_two_gemm_form(monkeypatch):
+    """heads_bf16_kernel (both 1x1 convs of a stage's heads in one launch, hidden tensor kept in registers) against the two
+    shared-tile GEMMs it replaces (LWP_FUSE_HEADS=0) and the fp32 oracle: initial stage (hidden 2 x 512) and refinement stage
+    (hidden 2 x 128), M = 2 x 12 x 19 pixels (not a multiple of the 128-row tile), NHWC concat-buffer window and NCHW outputs."""
+    sd = synth.make_state_dict(2, seed=3)
+    x = net_input(2, 92, 150, seed=401)[:, :, :91, :149].copy()
+    ref = net_ref.forward(sd, torch.from_numpy(x), 2)
+
+    def run(fuse):
+        monkeypatch.setenv("LWP_FUSE_HEADS", fuse)
+        net = PoseEstimationWithMobileNet(num_refinement_stages=2, dtype="bf16")
+        load_state(net, {"state_dict": sd})
+        net.eval().cuda()
+        names = [i for i in net.engine.layers() if i["name"].endswith(".heads.1")]
+        return net(x), {i["name"]: net.engine.debug_layer_output(x, i["index"]) for i in names}
+    fused, taps_f = run("1")
+    plain, taps_p = run("0")
+    assert len(taps_f) == 3
+    for f, q, r in zip(fused, plain, ref):
+        sc = max(1.0, float(r.abs().max()))
+        assert np.abs(f - r.numpy()).max() <= BF16_TOL * sc and np.abs(f - r.numpy()).mean() <= BF16_MEAN * sc
+        # same bf16 inputs and weights; the hidden values are rounded to bf16 in both forms, only the summation order differs
+        assert np.abs(f - q).max() <= 0.02 * sc
+    for nm in taps_f:                                     # the bf16 window written into the concat buffer
+        sc = max(1.0, float(np.abs(taps_p[nm]).max()))
+        assert np.abs(taps_f[nm] - taps_p[nm]).max() <= 0.03 * sc, nm
