@@ -545,10 +545,12 @@ static hipError_t launch_gemm_bf16_t(const GemmParams& p, hipStream_t s) {
 //     applied to the W1 fragment instead (two ds_read_b64 at columns 16 s + 4 h and 16 s + 8 + 4 h) — the hidden tile never
 //     touches LDS or another lane;
 //   - GEMM 2 (8 MFMAs per chunk) accumulates the 64 (57 used) output channels of the wave's 32 pixels over all chunks.
-constexpr int HD_BM = 128, HD_CH = 64, HD_K = 128;
+constexpr int HD_CH = 64, HD_K = 128;
 constexpr int HD_W0LD = HD_K + 8, HD_W1LD = HD_CH + 8;
 
+template <int RM>
 __global__ void __launch_bounds__(256) heads_bf16_kernel(HeadsParams p) {
+    constexpr int HD_BM = 128 * RM;                                  // wave = 32 RM pixels: every weight fragment read from LDS feeds RM MFMAs
     extern __shared__ __attribute__((aligned(16))) unsigned char hd_raw[];
     __bf16* W0s = (__bf16*)hd_raw;                                   // [2][64][HD_W0LD]
     __bf16* W1s = W0s + 2 * HD_CH * HD_W0LD;                         // [2][64][HD_W1LD]
@@ -561,8 +563,10 @@ __global__ void __launch_bounds__(256) heads_bf16_kernel(HeadsParams p) {
         const int nwg = gridDim.x, qq = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
         bid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
     }
-    const int m = bid * HD_BM + wave * 32 + i32;
-    const bool mok = m < M;
+    int mr[RM];
+    bool mok[RM];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) { mr[i] = bid * HD_BM + (wave * RM + i) * 32 + i32; mok[i] = mr[i] < M; }
     const int nch = p.hidden / HD_CH;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((int64_t)M * p.in_ld * 2), 0x00020000);
@@ -597,43 +601,55 @@ __global__ void __launch_bounds__(256) heads_bf16_kernel(HeadsParams p) {
     };
     request(0);
     // the wave's activations: k-slice s of pixel m = x[m][16 s + 8 h .. + 7]
-    bf16x8 xf[HD_K / 16];
+    bf16x8 xf[RM][HD_K / 16];
 #pragma unroll
-    for (int s = 0; s < HD_K / 16; ++s)
-        xf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, mok ? (unsigned)((m * p.in_ld + 16 * s + 8 * h) * 2) : 0x80000000u, 0, 0));
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int s = 0; s < HD_K / 16; ++s)
+            xf[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, mok[i] ? (unsigned)((mr[i] * p.in_ld + 16 * s + 8 * h) * 2) : 0x80000000u, 0, 0));
     for (int i = tid * 4; i < p.hidden; i += 256 * 4) *(f32x4*)(B0s + i) = *(const f32x4*)(p.b0 + i);
     land(0);
     __syncthreads();
 
-    f32x16 acc2[2];
+    f32x16 acc2[RM][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int i = 0; i < RM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc2[t][e] = 0.f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[i][t][e] = 0.f;
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
         request(c + 1 < nch ? c + 1 : c);                            // unconditional (the last chunk again): exact vmcnt counting
         __builtin_amdgcn_sched_barrier(0);                           // keep the requests ahead of the chunk's MFMAs
         const __bf16* w0 = W0s + (buf * HD_CH + i32) * HD_W0LD + 8 * h;
         const __bf16* w1 = W1s + (buf * 64 + i32) * HD_W1LD + 4 * h;
-        bf16x8 hf[2][2];
+        bf16x8 hf[RM][2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f32x16 acc1;
+            f32x16 acc1[RM];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int s = 0; s < HD_K / 16; ++s) {
-                const bf16x8 wv = *(const bf16x8*)(w0 + j * 32 * HD_W0LD + 16 * s);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xf[s], acc1, 0, 0, 0);
-            }
+                for (int e = 0; e < 16; ++e) acc1[i][e] = 0.f;
+            bf16x8 wv[HD_K / 16];                                    // all eight fragment reads in flight before the first MFMA
+#pragma unroll
+            for (int s = 0; s < HD_K / 16; ++s) wv[s] = *(const bf16x8*)(w0 + j * 32 * HD_W0LD + 16 * s);
+            __builtin_amdgcn_sched_barrier(0);                       // (the scheduler otherwise pairs every read with its MFMA again)
+#pragma unroll
+            for (int s = 0; s < HD_K / 16; ++s)
+#pragma unroll
+                for (int i = 0; i < RM; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[s], xf[i][s], acc1[i], 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 b = *(const f32x4*)(B0s + c * HD_CH + j * 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hf[j][g >> 1][(g & 1) * 4 + r] = (__bf16)fmaxf(acc1[4 * g + r] + b[r], 0.f);
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hf[i][j][g >> 1][(g & 1) * 4 + r] = (__bf16)fmaxf(acc1[i][4 * g + r] + b[r], 0.f);
             }
         }
+        bf16x8 w1v[2][2][2];                                         // the eight W1 fragments (hidden index permuted: see above)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -642,52 +658,83 @@ __global__ void __launch_bounds__(256) heads_bf16_kernel(HeadsParams p) {
                 for (int s = 0; s < 2; ++s) {
                     const __bf16* src = w1 + t * 32 * HD_W1LD + j * 32 + 16 * s;
                     const bf16x4 lo = *(const bf16x4*)src, hi = *(const bf16x4*)(src + 8);
-                    const bf16x8 wv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, hf[j][s], acc2[t], 0, 0, 0);
+                    w1v[t][j][s] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) acc2[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1v[t][j][s], hf[i][j][s], acc2[i][t], 0, 0, 0);
         if (c + 1 < nch) land(buf ^ 1);
         __syncthreads();
     }
 
     // epilogue: lane (pixel i32, half h) holds output channels 32 t + 8 g + 4 h + r
-    if (!mok) return;
     __bf16* out = (__bf16*)p.out;
     const int HW = p.H * p.W;
-    const int img = m / HW, pix = m - img * HW;
     const int c0 = p.out_split > 0 ? p.out_split : p.cout;
+    const bool out_vec = ((p.out_ld & 3) == 0) && ((((uintptr_t)out) & 7) == 0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int i = 0; i < RM; ++i) {
+        if (!mok[i]) continue;
+        const int m = mr[i];
+        const int img = m / HW, pix = m - img * HW;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = 32 * t + 8 * g + 4 * h;
-            const f32x4 b = *(const f32x4*)(p.b1 + n);
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ch = n + r;
-                if (ch >= p.cout) continue;
-                const float v = acc2[t][4 * g + r] + b[r];
-                out[(int64_t)m * p.out_ld + ch] = (__bf16)v;
-                if (ch < c0) { if (p.out_nchw) p.out_nchw[((int64_t)img * c0 + ch) * HW + pix] = v; }
-                else if (p.out_nchw2) p.out_nchw2[((int64_t)img * (p.cout - c0) + (ch - c0)) * HW + pix] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * t + 8 * g + 4 * h;
+                if (n >= p.cout) continue;
+                const f32x4 b = *(const f32x4*)(p.b1 + n);
+                const f32x4 v = {acc2[i][t][4 * g] + b[0], acc2[i][t][4 * g + 1] + b[1], acc2[i][t][4 * g + 2] + b[2], acc2[i][t][4 * g + 3] + b[3]};
+                if (out_vec && n + 3 < p.cout) {                 // 4 consecutive channels: one 8-byte store
+                    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *(bf16x4*)(out + (int64_t)m * p.out_ld + n) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.cout) out[(int64_t)m * p.out_ld + n + r] = (__bf16)v[r];
+                }
+                if (p.out_nchw || p.out_nchw2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ch = n + r;
+                        if (ch >= p.cout) continue;
+                        if (ch < c0) { if (p.out_nchw) p.out_nchw[((int64_t)img * c0 + ch) * HW + pix] = v[r]; }
+                        else if (p.out_nchw2) p.out_nchw2[((int64_t)img * (p.cout - c0) + (ch - c0)) * HW + pix] = v[r];
+                    }
+                }
             }
-        }
+    }
 }
 
 bool heads_bf16_supported(int cin_pad, int hidden, int cout_pad) {
     return cin_pad == HD_K && hidden % HD_CH == 0 && hidden >= HD_CH && hidden <= 4096 && cout_pad == 64;
 }
 
-hipError_t launch_heads_bf16(const HeadsParams& p, hipStream_t s) {
+template <int RM>
+static hipError_t launch_heads_bf16_t(const HeadsParams& p, hipStream_t s) {
+    constexpr int BM = 128 * RM;
     const int64_t M = (int64_t)p.N * p.H * p.W;
-    if (M >= (1ll << 31) - HD_BM || M * p.in_ld * 2 >= (1ll << 31) || (p.in_ld & 7)) return hipErrorInvalidValue;
+    if (M >= (1ll << 31) - BM || M * p.in_ld * 2 >= (1ll << 31) || (p.in_ld & 7)) return hipErrorInvalidValue;
     const size_t lds = (size_t)(2 * HD_CH * HD_W0LD + 2 * 64 * HD_W1LD) * 2 + (size_t)p.hidden * sizeof(float);
     static LdsAttrOnce attr;
     if (lds > 48 * 1024) {
-        hipError_t e = attr.ensure((const void*)heads_bf16_kernel, 96 * 1024);
+        hipError_t e = attr.ensure((const void*)heads_bf16_kernel<RM>, 96 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(heads_bf16_kernel, dim3((unsigned)((M + HD_BM - 1) / HD_BM)), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(heads_bf16_kernel<RM>, dim3((unsigned)((M + BM - 1) / BM)), dim3(256), lds, s, p);
     return hipGetLastError();
+}
+hipError_t launch_heads_bf16(const HeadsParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    static const char* env = getenv("LWP_HEADS_RM");           // experiments: rows per wave / 32
+    const int rm = env ? atoi(env) : 1;                       // 64 rows per wave (198 VGPRs, 2 waves per SIMD) measured 12-23 % slower
+    (void)M;
+    return rm == 2 ? launch_heads_bf16_t<2>(p, s) : launch_heads_bf16_t<1>(p, s);
 }
 
 // ---------------------------------------------------------------------------------------- implicit GEMM, activation window resident
