@@ -418,12 +418,12 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
     return LWP_OK;
 }
 
-// bf16: a stage's merged head pair (".heads.0" 1x1 C -> hidden + ReLU, ".heads.1" 1x1 hidden -> NH + NP) runs as one kernel
+// a stage's merged head pair (".heads.0" 1x1 C -> hidden + ReLU, ".heads.1" 1x1 hidden -> NH + NP) runs as one kernel
 // that keeps the hidden tensor on the CU.  LWP_FUSE_HEADS=0 launches the two GEMMs (A/B, tests).
-static bool heads_pair_fusable(lwp_context* h, size_t i) {
+static bool heads_pair_fusable(lwp_context* h, size_t i, int64_t M) {
     if (!h->fuse_heads) return false;
     const std::vector<Layer>& ls = h->g.layers;
-    if (h->dtype != LWP_BF16 || i + 1 >= ls.size()) return false;
+    if (i + 1 >= ls.size()) return false;
     const Layer& a = ls[i];
     const Layer& b = ls[i + 1];
     auto ends_with = [](const std::string& s, const char* suf) { const size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; };
@@ -431,7 +431,7 @@ static bool heads_pair_fusable(lwp_context* h, size_t i) {
     if (a.kind != L_GEMM || b.kind != L_GEMM || a.ks != 1 || b.ks != 1 || a.act != ACT_RELU || b.act != ACT_NONE) return false;
     if (a.res.buf >= 0 || b.res.buf >= 0 || a.out_index >= 0) return false;
     if (b.src.buf != a.dst.buf || b.src.coff != a.dst.coff || b.cin_pad != a.cout_pad || a.cout != a.cout_pad) return false;
-    return heads_bf16_supported(a.cin_pad, a.cout_pad, b.cout_pad);
+    return h->dtype == LWP_BF16 ? heads_bf16_supported(a.cin_pad, a.cout_pad, b.cout_pad) : heads_f32_supported(a.cin_pad, a.cout_pad, b.cout_pad, M);
 }
 
 static int enqueue_heads_pair(lwp_context* h, const Layer& a, const Layer& b, int N, int H, int W, float* const* d_outs_nchw) {
@@ -446,7 +446,7 @@ static int enqueue_heads_pair(lwp_context* h, const Layer& a, const Layer& b, in
     p.out_nchw2 = (b.out_index2 >= 0 && d_outs_nchw) ? d_outs_nchw[b.out_index2] : nullptr;
     p.out_split = b.out_split;
     p.N = N; p.H = dh; p.W = dw; p.hidden = a.cout_pad; p.cout = b.cout;
-    LAUNCH(h, KC_PW, launch_heads_bf16(p, h->stream));
+    LAUNCH(h, KC_PW, h->dtype == LWP_BF16 ? launch_heads_bf16(p, h->stream) : launch_heads_f32(p, h->stream));
     return LWP_OK;
 }
 
@@ -454,8 +454,11 @@ static int enqueue_heads_pair(lwp_context* h, const Layer& a, const Layer& b, in
 static int enqueue_forward(lwp_context* h, const float* d_in, int N, int H, int W, float* const* d_outs_nchw,
                            int max_layers = 1 << 30) {
     const std::vector<Layer>& ls = h->g.layers;
+    int fh, fw;
+    level_dims(H, W, 3, &fh, &fw);
+    const int64_t M3 = (int64_t)N * fh * fw;                 // pixels of the stride-8 maps the heads work on
     for (size_t i = 0; i < ls.size() && (int)i < max_layers; ++i) {
-        if ((int)i + 1 < max_layers && heads_pair_fusable(h, i)) {
+        if ((int)i + 1 < max_layers && heads_pair_fusable(h, i, M3)) {
             int rc = enqueue_heads_pair(h, ls[i], ls[i + 1], N, H, W, d_outs_nchw);
             if (rc) return rc;
             ++i;
@@ -1143,8 +1146,11 @@ extern "C" int lwp_debug_time_layer(lwp_handle h, int idx, int N, int H, int W, 
     if (rc) return rc;
     const Layer& l = h->g.layers[idx];
     // a fused head pair is timed at its first layer; its second layer has no launch of its own
-    const bool pair = heads_pair_fusable(h, (size_t)idx);
-    if (idx > 0 && heads_pair_fusable(h, (size_t)idx - 1)) { *ms_avg = 0.f; return LWP_OK; }
+    int fh, fw;
+    level_dims(H, W, 3, &fh, &fw);
+    const int64_t M3 = (int64_t)N * fh * fw;
+    const bool pair = heads_pair_fusable(h, (size_t)idx, M3);
+    if (idx > 0 && heads_pair_fusable(h, (size_t)idx - 1, M3)) { *ms_avg = 0.f; return LWP_OK; }
     auto one = [&]() { return pair ? enqueue_heads_pair(h, l, h->g.layers[idx + 1], N, H, W, nullptr) : enqueue_layer(h, l, h->d_in, N, H, W, nullptr); };
     hipEvent_t e0, e1;
     HIP_TRY(h, hipEventCreate(&e0));

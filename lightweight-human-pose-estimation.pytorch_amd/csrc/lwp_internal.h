@@ -140,6 +140,10 @@ struct HeadsParams {
 };
 bool heads_bf16_supported(int cin_pad, int hidden, int cout_pad);
 hipError_t launch_heads_bf16(const HeadsParams& p, hipStream_t s);
+// fp32 form for small M (batch 1: 3772 pixels): 16-pixel workgroups, the hidden dimension split over the waves, fixed-order
+// reduction of the partial outputs.  Pointers are f32 ([hidden][128], [64][hidden], NHWC f32 window).
+bool heads_f32_supported(int cin_pad, int hidden, int cout_pad, int64_t M);
+hipError_t launch_heads_f32(const HeadsParams& p, hipStream_t s);
 hipError_t launch_nchw_from_nhwc_bf16(const void* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, hipStream_t s);
 hipError_t launch_dw(const DwParams& p, hipStream_t s);

@@ -1312,6 +1312,131 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------------------- stage heads, both 1x1 convs in one kernel
+// out[m] = W1 . relu(W0 . x[m] + b0) + b1 (with_mobilenet.py:32-45, the merged heat / PAF pair) for small M (batch 1: 3772
+// pixels, where each of the two GEMM launches is mostly launch / ramp / tail).  Workgroup = 16 pixels x 8 waves; the hidden
+// dimension is split over the waves in tiles of 16 channels.  v_mfma_f32_16x16x4_f32 with the weights as the A operand:
+//   GEMM 1: D[hidden 16][pixel 16].  The summation index is free to permute: k-slot (step s = 4 u + c, lane group q) is read as
+//           input channel 32 q + 4 u + c, so a lane's operands are 128 contiguous bytes of its own row — eight 16-byte loads of
+//           the PLAIN [hidden][128] weight rows (fully coalesced, no packing), and of the pixel's own NHWC row, kept for all tiles.
+//   D leaves lane (pixel i, q) with hidden channels 4 q + r, r = 0..3: after bias + ReLU, register r IS the B operand of GEMM 2's
+//   step r if k-slot q of that step means hidden 4 q + r — i.e. the W1 fragment of lane (out channel i, q) is the 16-byte vector
+//   W1[out][16 tile + 4 q .. + 3].  The hidden values never leave the lane's registers.
+//   GEMM 2 accumulates all 64 (57 used) output channels per wave over its hidden tiles; the NW partial results are summed in the
+//   fixed order 0..NW-1 through LDS.  Weight loads are buffer loads with wave-uniform tile offsets, requested one tile ahead.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];     // [NW][4][64] f32x4 partial outputs
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int M = p.N * p.H * p.W;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    }
+    const int m = bid * 16 + i16;
+    const bool mok = m < M;
+    const float* in = (const float*)p.in;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((int64_t)M * p.in_ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w0r = __builtin_amdgcn_make_buffer_rsrc((void*)p.w0, 0, p.hidden * 128 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, 64 * p.hidden * 4, 0x00020000);
+    auto ld = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); };
+
+    const int ntiles = p.hidden / 16;
+    const int my = wave < ntiles ? (ntiles - wave + NW - 1) / NW : 0;            // tiles wave, wave + NW, ...
+    f32x4 w0v[2][8], w1v[2][4], b0v[2];
+    const __amdgpu_buffer_rsrc_t b0r = __builtin_amdgcn_make_buffer_rsrc((void*)p.b0, 0, p.hidden * 4, 0x00020000);
+    const unsigned w0_lane = (unsigned)(i16 * 128 + 32 * q) * 4u, w1_lane = (unsigned)(i16 * p.hidden + 4 * q) * 4u;
+    auto request = [&](int k, f32x4* a, f32x4* b, f32x4* bias) {                               // k-th tile of this wave (clamped: no branch around loads)
+        const int ht = wave + (k < my ? k : (my > 0 ? my - 1 : 0)) * NW;
+        const int htc = ht < ntiles ? ht : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = ld(w0r, w0_lane + 16u * u, (unsigned)htc * (16u * 128u * 4u));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = ld(w1r, w1_lane + (unsigned)(t * 16 * p.hidden) * 4u, (unsigned)htc * 64u);
+        *bias = ld(b0r, 16u * q, (unsigned)htc * 64u);                               // the tile's bias rides with its weights (exact vmcnt counting)
+    };
+    request(0, w0v[0], w1v[0], &b0v[0]);
+    f32x4 xf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xf[u] = ld(xr, mok ? (unsigned)((m * p.in_ld + 32 * q + 4 * u) * 4) : 0x80000000u, 0);
+
+    f32x4 acc2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto one = [&](int k, auto P_) {
+        constexpr int P = decltype(P_)::value;
+        request(k + 1, w0v[P ^ 1], w1v[P ^ 1], &b0v[P ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 b0 = b0v[P];
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0v[P][u][c], xf[u][c], acc1, 0, 0, 0);
+        f32x4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = fmaxf(acc1[r] + b0[r], 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[P][t][r], hv[r], acc2[t], 0, 0, 0);
+    };
+    int k = 0;
+    for (; k + 2 <= my; k += 2) {
+        one(k, std::integral_constant<int, 0>{});
+        one(k + 1, std::integral_constant<int, 1>{});
+    }
+    if (k < my) one(k, std::integral_constant<int, 0>{});
+
+    // fixed-order reduction of the NW partial tiles: [wave][t][lane] f32x4
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *(f32x4*)(hsm + ((wave * 4 + t) * 64 + lane) * 4) = acc2[t];
+    __syncthreads();
+    if (tid >= 256) return;
+    const int t = tid >> 6;                                   // output-channel tile of this thread (its lane keeps pixel / q)
+    f32x4 v = *(const f32x4*)(hsm + ((0 * 4 + t) * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += *(const f32x4*)(hsm + ((w * 4 + t) * 64 + lane) * 4);
+    const int n = 16 * t + 4 * q;                             // lane (pixel i16, q) holds output channels n .. n + 3
+    if (!mok || n >= p.cout) return;
+    v += *(const f32x4*)(p.b1 + n);
+    float* out = (float*)p.out;
+    if (((p.out_ld & 3) == 0) && ((((uintptr_t)out) & 15) == 0) && n + 3 < p.cout) *(f32x4*)(out + (int64_t)m * p.out_ld + n) = v;
+    else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < p.cout) out[(int64_t)m * p.out_ld + n + r] = v[r];
+    }
+    if (p.out_nchw || p.out_nchw2) {
+        const int HW = p.H * p.W;
+        const int img = m / HW, pix = m - img * HW;
+        const int c0 = p.out_split > 0 ? p.out_split : p.cout;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ch = n + r;
+            if (ch >= p.cout) continue;
+            if (ch < c0) { if (p.out_nchw) p.out_nchw[((int64_t)img * c0 + ch) * HW + pix] = v[r]; }
+            else if (p.out_nchw2) p.out_nchw2[((int64_t)img * (p.cout - c0) + (ch - c0)) * HW + pix] = v[r];
+        }
+    }
+}
+
+bool heads_f32_supported(int cin_pad, int hidden, int cout_pad, int64_t M) {
+    // every 16-pixel workgroup streams all of W0 and W1 (768 KB for the initial stage): only while the grid is ~2 rounds of the chip
+    return cin_pad == 128 && hidden % 16 == 0 && hidden >= 128 && hidden <= 4096 && cout_pad == 64 && M <= 8192;
+}
+
+hipError_t launch_heads_f32(const HeadsParams& p, hipStream_t s) {
+    constexpr int NW = 8;
+    const int64_t M = (int64_t)p.N * p.H * p.W;
+    if (M * p.in_ld * 4 >= (1ll << 31) || (p.in_ld & 3)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)NW * 4 * 64 * 4 * sizeof(float);
+    hipLaunchKernelGGL(heads_f32_kernel<NW>, dim3((unsigned)((M + 15) / 16)), dim3(NW * 64), lds, s, p);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------- layout helper
 __global__ void __launch_bounds__(256) nchw_from_nhwc_kernel(const float* src, int src_ld, float* dst, int N, int HW, int C) {
     const int64_t total = (int64_t)N * C * HW;

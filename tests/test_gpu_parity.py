@@ -906,3 +906,31 @@ def test_bf16_fused_head_pair_matches_the_two_gemm_form(monkeypatch):
     for nm in taps_f:                                     # the bf16 window written into the concat buffer
         sc = max(1.0, float(np.abs(taps_p[nm]).max()))
         assert np.abs(taps_f[nm] - taps_p[nm]).max() <= 0.03 * sc, nm
+
+
+@pytest.mark.gpu
+def test_fp32_fused_head_pair_matches_the_two_gemm_form(monkeypatch):
+    """heads_f32_kernel (small M: 16-pixel workgroups, hidden dimension split over 8 waves, fixed-order reduction) against the two
+    GEMM launches it replaces (LWP_FUSE_HEADS=0) and the oracle; M = 2 x 12 x 19 pixels (ragged last workgroup), nref 2."""
+    sd = synth.make_state_dict(2, seed=3)
+    x = net_input(2, 92, 150, seed=401)[:, :, :91, :149].copy()
+    ref = net_ref.forward(sd, torch.from_numpy(x), 2)
+
+    def run(fuse):
+        monkeypatch.setenv("LWP_FUSE_HEADS", fuse)
+        net = PoseEstimationWithMobileNet(num_refinement_stages=2)
+        load_state(net, {"state_dict": sd})
+        net.eval().cuda()
+        names = [i for i in net.engine.layers() if i["name"].endswith(".heads.1")]
+        return net(x), {i["name"]: net.engine.debug_layer_output(x, i["index"]) for i in names}
+    fused, taps_f = run("1")
+    plain, taps_p = run("0")
+    assert len(taps_f) == 3
+    for f, q, r in zip(fused, plain, ref):
+        sc = max(1.0, float(r.abs().max()))
+        assert np.abs(f - r.numpy()).max() <= NET_TOL * sc
+        assert np.abs(f - q).max() <= NET_TOL * sc
+    for nm in taps_f:
+        sc = max(1.0, float(np.abs(taps_p[nm]).max()))
+        assert np.abs(taps_f[nm] - taps_p[nm]).max() <= NET_TOL * sc, nm
+    assert any(not np.array_equal(taps_f[nm], taps_p[nm]) for nm in taps_f)      # it really is a different kernel

@@ -1,4 +1,5 @@
-python tools/layer_sweep.py 32 bf16 "X=1" cpm.align cpm.conv initial_stage.heads.0 initial_stage.heads.1 refinement_stages.0.trunk.0.initial refinement_stages.0.trunk.1.initial refinement_stages.0.trunk.0.trunk.1 refinement_stages.0.heads.0 refinement_stages.0.heads.1
+python tools/layer_sweep.py 1 fp32 "X=1;LWP_FUSE_HEADS=0" initial_stage.heads.0 initial_stage.heads.1 refinement_stages.0.heads.0 refinement_stages.0.heads.1
 B="python bench.py --no-cpu-baseline --no-extra-configs --min-time 2"
 f() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value'],1), d['ms_per_step'])"; }
-$B --batch 32 --dtype bf16 --streams 2 | f bf16_b32_s2
+$B | f base3
+$B --streams 1 | f base1
