@@ -48,7 +48,7 @@ def layer_class(l):
 
 # kernel-name fragments of every family (rocprofv3 kernel_stats rows are matched with these)
 KERNEL_NAMES = {"stem": ("stem_kernel",), "fused_dw_pw": ("dwpw_kernel", "dwpw_bf16_kernel"), "depthwise": ("dw_kernel", "dw_tiled_kernel"),
-                "gemm_1x1": ("gemm_ar_kernel", "gemm_wp_kernel", "gemm_kernel", "gemm_bf16_kernel", "gemm_bf16_ar_kernel"),
+                "gemm_1x1": ("gemm_ar_kernel", "gemm_wp_kernel", "gemm_kernel", "gemm_bf16_kernel", "gemm_bf16_ar_kernel", "heads_f32_kernel", "heads_bf16_kernel"),
                 "dense_3x3": ("gemm_ar_kernel", "gemm_wp_kernel", "gemm_kernel", "gemm_bf16_kernel", "gemm_bf16_ar_kernel")}
 
 
@@ -94,7 +94,7 @@ def rocprof_average_us(family, dtype):
         nm = row["Name"]
         if not any(frag + "<" in nm for frag in KERNEL_NAMES[family]):
             continue
-        if family in ("gemm_1x1", "dense_3x3"):
+        if family in ("gemm_1x1", "dense_3x3") and "heads_" not in nm:
             m = re.search(r"<([^>]*)>", nm)
             last = m.group(1).split(",")[-1].strip() if m else ""
             if last != ("3" if family == "dense_3x3" else "1"):

@@ -193,8 +193,9 @@ int lwp_time_pipeline(lwp_handle h, const float* in_device, int N, int H, int W,
  * ms[6], launches[6] out. */
 int lwp_profile_classes(lwp_handle h, const float* in_device, int N, int H, int W, int upsample_ratio,
                         int demo, int reps, float* ms, int* launches);
-/* per-launch device time of one pass (averaged over reps): ms[i], kclass[i] for launch i in issue order
- * (the first lwp_layer_count launches are the layers, the rest the post-processing kernels). */
+/* per-launch device time of one pass (averaged over reps): ms[i], kclass[i] for launch i in issue order.
+ * kclass[i] & 0xff = kernel class as above; kclass[i] >> 8 = 1 + index of the first layer the launch covers
+ * (a fused head pair is ONE launch covering two layers), 0 for a post-processing kernel. */
 int lwp_profile_launches(lwp_handle h, const float* in_device, int N, int H, int W, int upsample_ratio,
                          int demo, int reps, float* ms, int* kclass, int cap, int* n_launches);
 int lwp_synchronize(lwp_handle h);

@@ -59,6 +59,8 @@ struct lwp_context {
     bool profiling = false;
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_class;
+    std::vector<int> ev_layer;             // index of the (first) layer a launch covers, -1: post-processing kernel
+    int cur_layer = -1;
     size_t ev_used = 0;
     std::string err;
 };
@@ -346,8 +348,10 @@ static int prof_begin(lwp_context* h, int kclass) {
             h->ev.push_back(e);
         }
         h->ev_class.resize(h->ev.size() / 2);
+        h->ev_layer.resize(h->ev.size() / 2);
     }
     h->ev_class[h->ev_used / 2] = kclass;
+    h->ev_layer[h->ev_used / 2] = h->cur_layer;
     HIP_TRY(h, hipEventRecord(h->ev[h->ev_used], h->stream));
     return LWP_OK;
 }
@@ -458,6 +462,7 @@ static int enqueue_forward(lwp_context* h, const float* d_in, int N, int H, int 
     level_dims(H, W, 3, &fh, &fw);
     const int64_t M3 = (int64_t)N * fh * fw;                 // pixels of the stride-8 maps the heads work on
     for (size_t i = 0; i < ls.size() && (int)i < max_layers; ++i) {
+        h->cur_layer = (int)i;
         if ((int)i + 1 < max_layers && heads_pair_fusable(h, i, M3)) {
             int rc = enqueue_heads_pair(h, ls[i], ls[i + 1], N, H, W, d_outs_nchw);
             if (rc) return rc;
@@ -467,6 +472,7 @@ static int enqueue_forward(lwp_context* h, const float* d_in, int N, int H, int 
         int rc = enqueue_layer(h, ls[i], d_in, N, H, W, d_outs_nchw);
         if (rc) return rc;
     }
+    h->cur_layer = -1;
     return LWP_OK;
 }
 
@@ -1220,7 +1226,7 @@ extern "C" int lwp_profile_launches(lwp_handle h, const float* in_device, int N,
             float t = 0.f;
             HIP_TRY(h, hipEventElapsedTime(&t, h->ev[2 * i], h->ev[2 * i + 1]));
             ms[i] += t / (float)reps;
-            kclass[i] = h->ev_class[i];
+            kclass[i] = h->ev_class[i] | ((h->ev_layer[i] + 1) << 8);
         }
     }
     *n_launches = (int)nl;

@@ -387,8 +387,16 @@ class Engine(object):
         check(lib().lwp_profile_launches(self.h.ptr, x_cuda.data_ptr(), N, H, W, upsample_ratio, 1 if demo else 0, reps, ms, kc, cap, C.byref(n)), self.h.ptr)
         layers = self.layers()
         post = ["find_peaks", "nms", "score_pairs", "match", "assemble"]
-        names = [l["name"] for l in layers] + post
-        return [(names[i] if i < len(names) else "launch%d" % i, kc[i], ms[i]) for i in range(n.value)]
+        out, npost = [], 0
+        for i in range(n.value):
+            li = (kc[i] >> 8) - 1                      # first layer the launch covers (a fused head pair is one launch), -1: post kernel
+            if li >= 0:
+                name = layers[li]["name"]
+            else:
+                name = post[npost] if npost < len(post) else "launch%d" % i
+                npost += 1
+            out.append((name, kc[i] & 0xff, ms[i]))
+        return out
 
     def profile_classes(self, x_cuda, reps=5, upsample_ratio=4, demo=True):
         x_cuda = self._as_device_input(x_cuda)

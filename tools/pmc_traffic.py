@@ -22,6 +22,8 @@ def kernel_class(name):
         return "stem"
     if "dwpw" in name:
         return "fused_dw_pw"
+    if "heads_" in name:                           # a stage's two 1x1 head convs in one launch
+        return "gemm_1x1"
     if "gemm" in name:
         m = re.search(r"<([^>]*)>", name)
         args = [a.strip() for a in m.group(1).split(",")] if m else []

@@ -29,25 +29,32 @@ h, w = a.height, a.width
 eb = 4 if a.dtype == "fp32" else 2
 tot = 0.0
 print("%-40s %-4s %12s %9s %10s" % ("launch", "cls", "shape", "us", "rate"))
-for i, (name, kc, ms) in enumerate(rows):
+by_name = {l["name"]: i for i, l in enumerate(layers)}
+dims, hh, ww = [], a.height, a.width            # output map of every layer
+for l in layers:
+    if l["stride"] == 2:
+        hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+    dims.append((hh, ww))
+for name, kc, ms in rows:
     tot += ms
-    if i < len(layers):
-        l = layers[i]
-        if l["stride"] == 2:
-            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if name in by_name:
+        li = by_name[name]
+        l = layers[li]
+        h, w = dims[li]
         m = a.batch * h * w
-        if l["kind"] == 3:
-            fl = 2.0 * m * l["macs_per_pixel"]
-            rate = "%7.1f TF" % (fl / (ms * 1e-3) / 1e12)
-        elif l["kind"] == 2:
-            fl = 2.0 * m * l["macs_per_pixel"]
-            rate = "%7.1f TF" % (fl / (ms * 1e-3) / 1e12)
+        macs, cout, label = l["macs_per_pixel"], l["cout"], name
+        if name.endswith(".heads.0") and ms > 0 and li + 1 < len(layers) and not any(r[0] == layers[li + 1]["name"] for r in rows):
+            macs += layers[li + 1]["macs_per_pixel"]          # fused head pair: one launch covers both 1x1 convs
+            cout, label = layers[li + 1]["cout"], name[:-2] + "{0,1}"
+        if l["kind"] in (2, 3):
+            rate = "%7.1f TF" % (2.0 * m * macs / (ms * 1e-3) / 1e12)
         elif l["kind"] == 1:
             by = (m * l["stride"] ** 2 * l["cin"] + m * l["cout"] + 9 * l["cin"]) * eb
             rate = "%7.0f GB/s" % (by / (ms * 1e-3) / 1e9)
         else:
             rate = ""
-        shape = "%dx%d %d>%d k%d" % (h, w, l["cin"], l["cout"], l["ksize"])
+        shape = "%dx%d %d>%d k%d" % (h, w, l["cin"], cout, l["ksize"])
+        name = label
     else:
         rate, shape = "", ""
     print("%-40s %-4d %12s %9.1f %10s" % (name, kc, shape, ms * 1e3, rate))
