@@ -1120,15 +1120,21 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) wv[t] = *(const f32x4*)(p.dw_w + t * p.C + c);
         const f32x4 bias = *(const f32x4*)(p.dw_w + 9 * p.C + c);
+        // input loads are buffer loads (wave-uniform descriptor, one 32-bit byte offset per lane; a tap outside the image gets
+        // offset 2^31 >= num_records and reads zeros): while other workgroups of the CU are in their MFMA phase a 64-bit
+        // per-lane address costs ~3x the issue time
+        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4), 0x00020000);
+        const int pix_b = p.in_ld * 4, row_b = p.Wi * pix_b;
+        auto ldw = [&](unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0)); };
         for (int grp = tid / cg; grp < BM / PXG; grp += NT / cg) {
             const int row0 = grp * PXG;
             const int64_t m = m0 + row0;
             const bool ok0 = m < M;
             const int64_t mm = ok0 ? m : 0;
             const int xo = (int)(mm % p.Wo), yo = (int)((mm / p.Wo) % p.Ho);
-            const int64_t img = mm / ((int64_t)p.Wo * p.Ho);
+            const int img = (int)(mm / ((int64_t)p.Wo * p.Ho));
             if (p.stride == 1 && p.dil == 1 && m + PXG <= M && xo + PXG <= p.Wo) {
-                const float* base = p.in + ((img * p.Hi + yo) * p.Wi + xo) * p.in_ld + c;
+                const int base = ((img * p.Hi + yo) * p.Wi + xo) * pix_b + c * 4;
                 f32x4 win[3][PXG + 2];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
@@ -1137,8 +1143,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 #pragma unroll
                     for (int j = 0; j < PXG + 2; ++j) {
                         const int xx = xo + j - 1;
-                        const float* src = (rok && xx >= 0 && xx < p.Wi) ? base + ((int64_t)(ky - 1) * p.Wi + (j - 1)) * p.in_ld : p.zeros;
-                        win[ky][j] = *(const f32x4*)src;
+                        win[ky][j] = ldw((rok && xx >= 0 && xx < p.Wi) ? (unsigned)(base + (ky - 1) * row_b + (j - 1) * pix_b) : 0x80000000u);
                     }
                 }
 #pragma unroll
@@ -1158,16 +1163,15 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
                 const bool ok = mi < M;
                 const int64_t mq = ok ? mi : 0;
                 const int xi = (int)(mq % p.Wo), yi = (int)((mq / p.Wo) % p.Ho);
-                const int64_t im = mq / ((int64_t)p.Wo * p.Ho);
+                const int im = (int)(mq / ((int64_t)p.Wo * p.Ho));
                 const int yc = yi * p.stride, xc = xi * p.stride;
-                const float* base = p.in + ((im * p.Hi + yc) * p.Wi + xc) * p.in_ld + c;
+                const int base = ((im * p.Hi + yc) * p.Wi + xc) * pix_b + c * 4;
                 f32x4 x[9];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
                     const bool in = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
-                    const float* src = in ? base + ((int64_t)dy * p.Wi + dx) * p.in_ld : p.zeros;   // select on the address
-                    x[t] = *(const f32x4*)src;
+                    x[t] = ldw(in ? (unsigned)(base + dy * row_b + dx * pix_b) : 0x80000000u);
                 }
                 f32x4 acc = bias;
 #pragma unroll
@@ -1262,6 +1266,7 @@ static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     size_t lds = (size_t)BM * (p.C + 4) * sizeof(float);
     if (DBG & 256) lds += (size_t)NW * 4096;
+    if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4 >= (1ll << 31)) return hipErrorInvalidValue;     // 32-bit buffer offsets (2 GiB of input per launch)
     const int nsplit = (p.cout / 32) / NW;
     static LdsAttrOnce attr;
     if (lds > 48 * 1024) {
