@@ -593,7 +593,30 @@ def measure_extras(out, args, eng, engines, net, sd, x, x_np, step, run_steps, l
             one(i)
         torch.cuda.synchronize()
         t2 = (time.perf_counter() - t1) / 100
-        return {"frames_per_s": 1.0 / t2, "ms_per_step": t2 * 1e3, "note": "uint8 HxWx3 host frame -> H2D -> lwp_preprocess_u8 -> network + grouping -> host; serial, 1 stream"}
+
+        def piped(k):                             # the headline's protocol from the same boundary: len(engines) frames in flight
+            E, pending, r = len(engines), [], None
+            for i in range(k):
+                e, slot = engines[i % E], (i // E) & 1
+                if len(pending) >= 2 * E:
+                    pe, ps = pending.pop(0)
+                    r = pe.pipeline_fetch(ps)
+                xx, _, _ = e.preprocess_u8(fr[i % 4], args.height, 8)
+                e.pipeline_submit(xx, slot, 4, True)
+                pending.append((e, slot))
+            for pe, ps in pending:
+                r = pe.pipeline_fetch(ps)
+            return r
+        ent = {"frames_per_s": 1.0 / t2, "ms_per_step": t2 * 1e3, "note": "uint8 HxWx3 host frame -> H2D -> lwp_preprocess_u8 -> network + grouping -> host; serial, 1 stream"}
+        if not args.no_pipeline and len(engines) > 1:
+            piped(12)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            piped(300)
+            torch.cuda.synchronize()
+            t3 = (time.perf_counter() - t1) / 300
+            ent["pipelined"] = {"frames_per_s": 1.0 / t3, "ms_per_step": t3 * 1e3, "note": "same boundary, %d frames in flight (the headline's engine streams)" % len(engines)}
+        return ent
     if args.batch == 1 and args.dtype == "fp32":
         guarded("batch1_fp32_u8_input", u8_input)
 
