@@ -230,8 +230,10 @@ __global__ void __launch_bounds__(256) dw_tiled_kernel(DwParams p, int tiles_y, 
     const int n = blockIdx.x / per_img, r0 = blockIdx.x - n * per_img;
     const int ty0 = (r0 / tiles_x) * PH, tx0 = (r0 % tiles_x) * PW;
     const int y0 = ty0 * S - D, x0 = tx0 * S - D;     // input position of window (0, 0)
-    const float* img = p.in + (int64_t)n * p.Hi * p.Wi * p.in_ld + c0;
-    // ---- stage the window: piece = (window pixel, 16-byte part); all loads of a thread are issued before its stores
+    // ---- stage the window: piece = (window pixel, 16-byte part); all loads of a thread are issued before its stores.
+    // Buffer loads: wave-uniform descriptor, one 32-bit byte offset per lane; a piece outside the image gets offset 2^31
+    // (>= num_records: the hardware returns zeros) — no exec-masked 64-bit-address loads
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4), 0x00020000);
     constexpr int NPIECE = WR * WC * QN, PPT = (NPIECE + 255) / 256;
     f32x4 pc[PPT];
 #pragma unroll
@@ -241,7 +243,8 @@ __global__ void __launch_bounds__(256) dw_tiled_kernel(DwParams p, int tiles_y, 
         const int wy = px / WC, wx = px % WC;
         const int y = y0 + wy, x = x0 + wx;
         const bool ok = i < NPIECE && y >= 0 && y < p.Hi && x >= 0 && x < p.Wi;
-        pc[u] = ok ? *(const f32x4*)(img + ((int64_t)y * p.Wi + x) * p.in_ld + part * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned off = ok ? (unsigned)((((n * p.Hi + y) * p.Wi + x) * p.in_ld + c0 + part * 4) * 4) : 0x80000000u;
+        pc[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0));
     }
     const int cq = tid % QN, lx = (tid / QN) % PW, grp = tid / (QN * PW);
     const int c = c0 + cq * 4;
@@ -319,6 +322,7 @@ static hipError_t launch_dw_tiled_t(const DwParams& p, hipStream_t s) {
     const int tiles_y = (p.Ho + PH - 1) / PH, tiles_x = (p.Wo + 7) / 8;
     const int64_t tiles = (int64_t)p.N * tiles_y * tiles_x;
     if (tiles >= (1ll << 31) - 1) return hipErrorInvalidValue;
+    if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4 >= (1ll << 31)) return hipErrorInvalidValue;      // 32-bit buffer offsets
     static LdsAttrOnce attr;
     if (lds > 48 * 1024) { hipError_t e = attr.ensure((const void*)dw_tiled_kernel<CC, S, D, PH>, 96 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL((dw_tiled_kernel<CC, S, D, PH>), dim3((unsigned)tiles, p.C / CC), dim3(256), lds, s, p, tiles_y, tiles_x);
@@ -337,6 +341,7 @@ static hipError_t try_dw_tiled(const DwParams& p, hipStream_t s, bool* used) {
     const int cc = p.C % 64 == 0 ? 64 : (p.C % 32 == 0 ? 32 : 0);
     if (!cc) return hipSuccess;
     if (p.C / cc > 65535 || pixels >= (1ll << 31)) return hipSuccess;
+    if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4 >= (1ll << 31)) return hipSuccess;       // the tiled kernel addresses its input with 32-bit buffer offsets
     // 16-row patches pay on the first block only (32 channels: 128-byte pixel rows, 30k workgroups): 4.05 -> 5.09 TB/s; the
     // 46 x 82 layers lose with them (cpm.trunk 4.6 -> 3.7 TB/s)
     static const char* phenv = getenv("LWP_DW_PH");           // patch rows 8 | 16 (experiments)
