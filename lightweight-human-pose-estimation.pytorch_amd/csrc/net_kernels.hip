@@ -338,7 +338,13 @@ static hipError_t try_dw_tiled(const DwParams& p, hipStream_t s, bool* used) {
     if (!force && pixels * p.C < (int64_t)8 * 1024 * 1024) return hipSuccess;       // small maps: the per-thread kernel fills the chip better
     if ((p.stride != 1 && p.stride != 2) || (p.dil != 1 && p.dil != 2) || (p.in_ld & 3) || (p.out_ld & 3)) return hipSuccess;
     if (p.stride == 2 && p.dil == 2) return hipSuccess;
-    const int cc = p.C % 64 == 0 ? 64 : (p.C % 32 == 0 ? 32 : 0);
+    static const char* ccenv = getenv("LWP_DW_CC");           // channels per workgroup: "128" | "64" everywhere it applies (experiments)
+    int cc = p.C % 64 == 0 ? 64 : (p.C % 32 == 0 ? 32 : 0);
+    // 128 channels per workgroup (512-byte pieces of the 2-KB pixel rows) measured at batch 32: the 512-channel blocks 4.68 -> 4.90
+    // TB/s and model.3 (128 channels, 92 x 164) 4.76 -> 4.91; 256 channels 5.18 -> 4.90, dilation 2 4.16 -> 3.96 and the small
+    // 128-channel maps 4.68 -> 3.85 lose with it
+    const bool want128 = p.stride == 1 && p.dil == 1 && p.C % 128 == 0 && (p.C >= 512 || (p.C == 128 && pixels * p.C >= (int64_t)32 * 1024 * 1024));
+    if (ccenv ? (atoi(ccenv) == 128 && p.C % 128 == 0 && p.stride == 1) : want128) cc = 128;
     if (!cc) return hipSuccess;
     if (p.C / cc > 65535 || pixels >= (1ll << 31)) return hipSuccess;
     if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4 >= (1ll << 31)) return hipSuccess;       // the tiled kernel addresses its input with 32-bit buffer offsets
@@ -348,7 +354,7 @@ static hipError_t try_dw_tiled(const DwParams& p, hipStream_t s, bool* used) {
     const int ph = phenv ? atoi(phenv) : (cc == 32 ? 16 : 8);
     *used = true;
 #define DT_CASE(CC_, S_, D_) if (cc == CC_ && p.stride == S_ && p.dil == D_) return ph == 16 && S_ == 1 ? launch_dw_tiled_t<CC_, S_, D_, 16>(p, s) : launch_dw_tiled_t<CC_, S_, D_, 8>(p, s);
-    DT_CASE(64, 1, 1) DT_CASE(64, 1, 2) DT_CASE(64, 2, 1) DT_CASE(32, 1, 1) DT_CASE(32, 1, 2) DT_CASE(32, 2, 1)
+    DT_CASE(64, 1, 1) DT_CASE(64, 1, 2) DT_CASE(64, 2, 1) DT_CASE(32, 1, 1) DT_CASE(32, 1, 2) DT_CASE(32, 2, 1) DT_CASE(128, 1, 1) DT_CASE(128, 1, 2)
 #undef DT_CASE
     *used = false;
     return hipSuccess;
