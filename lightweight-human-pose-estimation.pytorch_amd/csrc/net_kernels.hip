@@ -65,7 +65,27 @@ __global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
     const int n = blockIdx.y;
     const float* in = p.in + (int64_t)n * 3 * p.H * p.W;
     if (!(DBG & 1)) {
-        if ((p.W & 3) == 0 && (((uintptr_t)p.in) & 15) == 0) {
+        if ((p.W & 3) == 0 && (((uintptr_t)p.in) & 15) == 0 && (int64_t)p.N * 3 * p.H * p.W * 4 < (1ll << 31)) {
+            // every quad of the thread is requested before the first LDS store (buffer loads: one 32-bit offset per lane, a quad
+            // outside the image reads offset 2^31 >= num_records and comes back as zeros)
+            const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((int64_t)p.N * 3 * p.H * p.W * 4), 0x00020000);
+            constexpr int ITEMS = 3 * IR * IQ, PER = (ITEMS + NT - 1) / NT;
+            f32x4 v[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int i = tid + u * NT;
+                const int qd = i % IQ, r = (i / IQ) % IR, c = i / (IQ * IR);
+                const int yi = 2 * y0 - 1 + r, xi = 2 * x0 - 4 + 4 * qd;
+                const bool ok = i < ITEMS && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
+                v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, ok ? (unsigned)((((n * 3 + c) * p.H + yi) * p.W + xi) * 4) : 0x80000000u, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int i = tid + u * NT;
+                const int qd = i % IQ, r = (i / IQ) % IR, c = i / (IQ * IR);
+                if (i < ITEMS) *(f32x4*)(s_in + (c * IR + r) * ICP + 4 * qd) = v[u];
+            }
+        } else if ((p.W & 3) == 0 && (((uintptr_t)p.in) & 15) == 0) {
             for (int i = tid; i < 3 * IR * IQ; i += NT) {
                 const int qd = i % IQ, r = (i / IQ) % IR, c = i / (IQ * IR);
                 const int yi = 2 * y0 - 1 + r, xi = 2 * x0 - 4 + 4 * qd;
