@@ -105,11 +105,13 @@ __global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
     }
     __syncthreads();
     const int ty = tid / ST_TX, tx = tid % ST_TX;                  // the thread's pixels: rows ty*PY + j, column tx
-    float acc[PY][32];
+    // channel PAIRS per register pair: v_pk_fma_f32 does two of the 864 FMAs of a pixel per issue slot (a plain v_fmac of a
+    // 64-lane wave takes 4 cycles: 42 us of issue at batch 32); every output keeps its own fmaf chain in (ky, kx, ci) order
+    f32x2 acc2[PY][16];
 #pragma unroll
     for (int j = 0; j < PY; ++j)
 #pragma unroll
-        for (int o = 0; o < 32; ++o) acc[j][o] = p.bias[o];
+        for (int o = 0; o < 16; ++o) acc2[j][o] = f32x2{p.bias[2 * o], p.bias[2 * o + 1]};
 #pragma unroll
     for (int ky = 0; ky < ((DBG & 2) ? 0 : 3); ++ky)
 #pragma unroll
@@ -117,14 +119,19 @@ __global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {                       // (ky, kx, ci) order: the fmaf chain of every output is fixed
                 const float* w = p.w + ((ky * 3 + kx) * 3 + ci) * 32;      // uniform address: scalar loads
-                float v[PY];
+                f32x2 v[PY];
 #pragma unroll
-                for (int j = 0; j < PY; ++j) v[j] = s_in[(ci * IR + 2 * (ty * PY + j) + ky) * ICP + 2 * tx + 3 + kx];      // x = 2*(x0 + tx) - 1 + kx
+                for (int j = 0; j < PY; ++j) { const float x = s_in[(ci * IR + 2 * (ty * PY + j) + ky) * ICP + 2 * tx + 3 + kx]; v[j] = f32x2{x, x}; }      // x = 2*(x0 + tx) - 1 + kx
 #pragma unroll
-                for (int o = 0; o < 32; ++o)
+                for (int o = 0; o < 16; ++o)
 #pragma unroll
-                    for (int j = 0; j < PY; ++j) acc[j][o] = fmaf(v[j], w[o], acc[j][o]);
+                    for (int j = 0; j < PY; ++j) acc2[j][o] = __builtin_elementwise_fma(v[j], f32x2{w[2 * o], w[2 * o + 1]}, acc2[j][o]);
             }
+    float acc[PY][32];
+#pragma unroll
+    for (int j = 0; j < PY; ++j)
+#pragma unroll
+        for (int o = 0; o < 16; ++o) { acc[j][2 * o] = acc2[j][o][0]; acc[j][2 * o + 1] = acc2[j][o][1]; }
     constexpr int CPP = BF16 ? 4 : 8;                               // 16-byte chunks per pixel
 #pragma unroll
     for (int j = 0; j < PY; ++j) {
