@@ -1131,15 +1131,12 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 #endif
     constexpr int PF = DWPW_PF;
     f32x4 bw[PF][4];
-    f32x4 bx[(DBG & 32) ? PF : 1][4];
     auto load_b = [&](int step, f32x4* dst) {
         // buffer loads: the weights' descriptor and the step's offset are wave-uniform (SGPRs), a lane supplies one 32-bit offset
         // register; the global_load form needs a 64-bit address per lane
-        const unsigned soff = (DBG & 16) ? (unsigned)(step & 1) * 4096u                  // ablation: every wave re-reads the same 8 KiB (L1 hits)
-                                         : (unsigned)(step * nwt + wave_u) * 4096u;
-        const int nld = (DBG & 64) ? 2 : 4;                                             // ablation 64: half the bytes in half the instructions
+        const unsigned soff = (unsigned)(step * nwt + wave_u) * 4096u;
 #pragma unroll
-        for (int j = 0; j < nld; ++j)
+        for (int j = 0; j < 4; ++j)
             dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + j * 1024, soff, 0));
     };
 #pragma unroll
@@ -1233,14 +1230,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
     auto one = [&](int step, auto P_) {
         constexpr int P = decltype(P_)::value;
         const int nxt = step + PF - 1 < nsteps ? step + PF - 1 : nsteps - 1;
-        if (DBG & 256) {                              // ablation: the stream goes to LDS by LDS-DMA (no VGPR destination), never read
-            const float* src = p.pw_w + ((int64_t)(nxt * nwt + wave) * 4) * 256 + lane * 4;
-            __attribute__((address_space(3))) float* wl = (__attribute__((address_space(3))) float*)(At + BM * ldA) + (tid >> 6) * 1024;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(src + j * 256, wl + j * 256, 16, 0, 0);
-        } else
-        if (DBG & 32) load_b(nxt, bx[(P + PF - 1) % PF]);   // ablation: the stream is requested but never waited for
-        else if (!(DBG & 2)) load_b(nxt, bw[(P + PF - 1) % PF]);
+        if (!(DBG & 2)) load_b(nxt, bw[(P + PF - 1) % PF]);
         __builtin_amdgcn_sched_barrier(0);           // the scheduler otherwise sinks the requests below the MFMAs of this step
         if (DBG & 4) return;
         const f32x4* bcur = bw[P];
@@ -1272,14 +1262,6 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
     }
     if (s0 < nsteps) { one(s0, std::integral_constant<int, 0>{}); ++s0; }
     if (PF > 2 && s0 < nsteps) { one(s0, std::integral_constant<int, 1 % PF>{}); ++s0; }
-    if (DBG & 32) {
-        f32x4 sink = bx[0][0];
-#pragma unroll
-        for (int a = 0; a < ((DBG & 32) ? PF : 1); ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sink += bx[a][j];
-        if (p.N < 0) *(f32x4*)(p.out) = sink;           // never taken
-    }
     // epilogue: D layout row (channel) = (lane>>4)*4 + reg, col (pixel) = lane&15
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1302,8 +1284,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 template <int BM, int NW, int DBG = 0, int ACT = -1>
 static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
-    size_t lds = (size_t)BM * (p.C + 4) * sizeof(float);
-    if (DBG & 256) lds += (size_t)NW * 4096;
+    const size_t lds = (size_t)BM * (p.C + 4) * sizeof(float);
     if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4 >= (1ll << 31)) return hipErrorInvalidValue;     // 32-bit buffer offsets (2 GiB of input per launch)
     const int nsplit = (p.cout / 32) / NW;
     static LdsAttrOnce attr;
@@ -1340,7 +1321,7 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     static const char* dbg = getenv("LWP_DWPW_DEBUG");
     const int d = dbg ? atoi(dbg) : 0;
 #define DP_DBG(BM_, NW_, D_) if (bm == BM_ && nw_wg == NW_ && d == D_) return launch_dwpw_t<BM_, NW_, D_>(p, s);
-#define DP_DBGS(BM_, NW_) DP_DBG(BM_, NW_, 1) DP_DBG(BM_, NW_, 2) DP_DBG(BM_, NW_, 3) DP_DBG(BM_, NW_, 4) DP_DBG(BM_, NW_, 6) DP_DBG(BM_, NW_, 7) DP_DBG(BM_, NW_, 8) DP_DBG(BM_, NW_, 16) DP_DBG(BM_, NW_, 17) DP_DBG(BM_, NW_, 33) DP_DBG(BM_, NW_, 49) DP_DBG(BM_, NW_, 97) DP_DBG(BM_, NW_, 161) DP_DBG(BM_, NW_, 257)
+#define DP_DBGS(BM_, NW_) DP_DBG(BM_, NW_, 1) DP_DBG(BM_, NW_, 2) DP_DBG(BM_, NW_, 3) DP_DBG(BM_, NW_, 4) DP_DBG(BM_, NW_, 6) DP_DBG(BM_, NW_, 7) DP_DBG(BM_, NW_, 8)
     DP_DBGS(16, 16) DP_DBGS(16, 8) DP_DBGS(16, 4)
 #undef DP_DBGS
 #undef DP_DBG
