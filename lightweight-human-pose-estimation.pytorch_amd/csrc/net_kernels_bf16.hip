@@ -533,6 +533,10 @@ static hipError_t launch_gemm_bf16_t(const GemmParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Measured and dropped: the heads kernel's structure for the single 1x1 convs to 128 channels (cpm.align, refinement `initial`):
+// activations straight into MFMA operand registers (32-byte pieces of 32 pixel rows per request), only the weights through
+// LDS in 64-channel chunks, LDS-staged output — 36.8 / 21.7 / 21.1 us against 32.7 / 21.2 / 18.5 for the shared-tile kernel
+// with its staged epilogue (batch 32, K = 512 / 192 / 128).
 // ---------------------------------------------------------------------------------------- stage heads, both 1x1 convs in one kernel
 // out[m][0..NH+NP) = W1 . relu(W0 . x[m] + b0) + b1 with the hidden vector (1024 wide in the initial stage: 247 MB per tensor at
 // batch 32, written by one GEMM and read back by the next) kept on the CU.  Workgroup = 4 waves = 128 pixels, wave = 32 pixels:
