@@ -48,7 +48,10 @@ constexpr int ST_TX = 32;
 // (A persistent form that requests the next tile's quads before the FMAs was measured and dropped: 143 us against 104 —
 // the parked quads cost a wave of occupancy and, inside a tile loop, the weights are only scalar-loaded when read through
 // the constant address space.)
-template <bool BF16, int ST_TY, int PY = 1, int DBG = 0>
+// WL: the 27 x 32 weights are staged in LDS and read back as broadcast vectors instead of arriving through scalar loads.  With
+// one or two waves per SIMD (batch 1: 1012 one-wave workgroups) nothing hides the 54 dependent s_load_dwordx16 round trips
+// of a pixel; with four or more (batch 32) the scalar form is the cheaper one (no extra LDS instructions).
+template <bool BF16, int ST_TY, int PY = 1, int DBG = 0, bool WL = false>
 __global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
     constexpr int NT = ST_TY * ST_TX;
     constexpr int TROWS = ST_TY * PY;                              // output rows per tile
@@ -59,7 +62,11 @@ __global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
     __shared__ __attribute__((aligned(16))) float smem[IN_FLOATS > OUT_FLOATS ? IN_FLOATS : OUT_FLOATS];
     float* s_in = smem;                                            // [3][IR][ICP]
     float* s_out = smem;                                           // [NT][OLD]  (after the compute phase, one pixel of every thread at a time)
+    __shared__ __attribute__((aligned(16))) float s_w[WL ? 27 * 32 : 4];
     const int tid = threadIdx.x;
+    if (WL) {
+        for (int i = tid * 4; i < 27 * 32; i += NT * 4) *(f32x4*)(s_w + i) = *(const f32x4*)(p.w + i);
+    }
     const int tiles_x = (p.Wo + ST_TX - 1) / ST_TX;
     const int x0 = (blockIdx.x % tiles_x) * ST_TX, y0 = (blockIdx.x / tiles_x) * TROWS;
     const int n = blockIdx.y;
@@ -112,6 +119,27 @@ __global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
     for (int j = 0; j < PY; ++j)
 #pragma unroll
         for (int o = 0; o < 16; ++o) acc2[j][o] = f32x2{p.bias[2 * o], p.bias[2 * o + 1]};
+    if (WL) {
+        // the eight weight vectors of tap t + 1 are read (LDS broadcast) while tap t's sixteen packed FMAs issue
+        f32x4 wq[2][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wq[0][q] = *(const f32x4*)(s_w + 4 * q);
+#pragma unroll
+        for (int t = 0; t < ((DBG & 2) ? 0 : 27); ++t) {               // t = (ky * 3 + kx) * 3 + ci: the fmaf chain of every output is fixed
+            const int ky = t / 9, kx = (t / 3) % 3, ci = t % 3;
+            if (t + 1 < 27) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) wq[(t + 1) & 1][q] = *(const f32x4*)(s_w + (t + 1) * 32 + 4 * q);
+            }
+            f32x2 v[PY];
+#pragma unroll
+            for (int j = 0; j < PY; ++j) { const float x = s_in[(ci * IR + 2 * (ty * PY + j) + ky) * ICP + 2 * tx + 3 + kx]; v[j] = f32x2{x, x}; }
+#pragma unroll
+            for (int o = 0; o < 16; ++o)
+#pragma unroll
+                for (int j = 0; j < PY; ++j) acc2[j][o] = __builtin_elementwise_fma(v[j], f32x2{wq[t & 1][o >> 1][(o & 1) * 2], wq[t & 1][o >> 1][(o & 1) * 2 + 1]}, acc2[j][o]);
+        }
+    } else {
 #pragma unroll
     for (int ky = 0; ky < ((DBG & 2) ? 0 : 3); ++ky)
 #pragma unroll
@@ -127,6 +155,7 @@ __global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
 #pragma unroll
                     for (int j = 0; j < PY; ++j) acc2[j][o] = __builtin_elementwise_fma(v[j], f32x2{w[2 * o], w[2 * o + 1]}, acc2[j][o]);
             }
+    }
     float acc[PY][32];
 #pragma unroll
     for (int j = 0; j < PY; ++j)
@@ -165,6 +194,8 @@ static hipError_t launch_stem_t(const StemParams& p, hipStream_t s) {
     const int tx = (p.Wo + ST_TX - 1) / ST_TX;
     int ty = ((int64_t)tx * ((p.Ho + 7) / 8) * p.N >= 2048) ? 8 : (((int64_t)tx * ((p.Ho + 3) / 4) * p.N >= 2048) ? 4 : 2);
     if (env) ty = atoi(env);
+    static const char* wlenv = getenv("LWP_STEM_WL");         // "0" | "1": weights through scalar loads | LDS in the small-tile variants (A/B)
+    const bool wl = wlenv ? wlenv[0] == '1' : true;
 #ifdef LWP_ABLATION
     static const char* dbg = getenv("LWP_STEM_DEBUG");
     const int d = dbg ? atoi(dbg) : 0;
@@ -174,6 +205,8 @@ static hipError_t launch_stem_t(const StemParams& p, hipStream_t s) {
 #endif
     if (ty == 16) hipLaunchKernelGGL((stem_kernel<BF16, 8, 2>), dim3(tx * ((p.Ho + 15) / 16), p.N), dim3(256), 0, s, p);
     else if (ty == 8) hipLaunchKernelGGL((stem_kernel<BF16, 8>), dim3(tx * ((p.Ho + 7) / 8), p.N), dim3(256), 0, s, p);
+    else if (ty == 4 && wl) hipLaunchKernelGGL((stem_kernel<BF16, 4, 1, 0, true>), dim3(tx * ((p.Ho + 3) / 4), p.N), dim3(128), 0, s, p);
+    else if (ty == 2 && wl) hipLaunchKernelGGL((stem_kernel<BF16, 2, 1, 0, true>), dim3(tx * ((p.Ho + 1) / 2), p.N), dim3(64), 0, s, p);
     else if (ty == 4) hipLaunchKernelGGL((stem_kernel<BF16, 4>), dim3(tx * ((p.Ho + 3) / 4), p.N), dim3(128), 0, s, p);
     else if (ty == 2) hipLaunchKernelGGL((stem_kernel<BF16, 2>), dim3(tx * ((p.Ho + 1) / 2), p.N), dim3(64), 0, s, p);
     else return hipErrorInvalidValue;
