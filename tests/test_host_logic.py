@@ -362,3 +362,32 @@ def test_bench_multi_rank_protocol_over_gloo(tmp_path):
     assert abs(out["value"] - 6 * 6 / (out["ms_per_step"] * 6 / 1e3)) < 1e-6 * out["value"]
     assert out["timed_blocks"] == len(out["block_values"]) >= 2
     assert out["block_spread"]["min"] <= out["value"] <= out["block_spread"]["max"]
+
+
+def test_pose_draw_marks_joints_and_limbs_and_stays_inside_the_image():
+    """modules/pose.py:47-62 (`Pose.draw`: circles on the found key-points, a line per limb whose two ends were found).  The
+    rasteriser is the product's own (cv2 is absent): joints and limbs must be painted in `Pose.color`, missing key-points
+    (-1) and limbs with a missing end must not be, and points at / beyond the border must not raise or wrap around."""
+    from lwpose_amd.modules.pose import BODY_PARTS_KPT_IDS, Pose
+    kp = np.full((Pose.num_kpts, 2), -1, np.int32)
+    a, b = BODY_PARTS_KPT_IDS[0]
+    kp[a] = (10, 12)
+    kp[b] = (30, 12)                                   # a horizontal limb
+    c, d = BODY_PARTS_KPT_IDS[2]
+    if c not in (a, b):
+        kp[c] = (0, 0)                                 # a joint on the corner; its partner stays missing
+    img = np.zeros((40, 48, 3), np.uint8)
+    Pose(kp, 1.0).draw(img)
+    col = np.array(Pose.color, np.uint8)
+    assert (img[12, 10] == col).all() and (img[12, 30] == col).all()          # the joints
+    assert (img[12, 11:30] == col).all()                                      # every pixel of the limb between them
+    assert not img[30:, :].any() and not img[:, 40:].any()                    # nothing far from the pose
+    painted = np.argwhere(img.any(axis=2))
+    assert painted[:, 0].max() <= 12 + 3 and painted[:, 1].max() <= 30 + 3
+    if c not in (a, b):
+        assert (img[0, 0] == col).all()
+    far = np.full((Pose.num_kpts, 2), -1, np.int32)
+    far[a] = (47, 39)
+    far[b] = (60, 50)                                  # outside the image: clipped, no exception
+    Pose(far, 1.0).draw(img)
+    assert (img[39, 47] == col).all()
