@@ -934,3 +934,36 @@ def test_fp32_fused_head_pair_matches_the_two_gemm_form(monkeypatch):
         sc = max(1.0, float(np.abs(taps_p[nm]).max()))
         assert np.abs(taps_f[nm] - taps_p[nm]).max() <= NET_TOL * sc, nm
     assert any(not np.array_equal(taps_f[nm], taps_p[nm]) for nm in taps_f)      # it really is a different kernel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,NH,NP", [(96, 19, 38), (64, 17, 30)])
+def test_fp32_non_default_channel_counts_match_the_oracle(C, NH, NP):
+    """The constructor's other arguments (with_mobilenet.py:89: num_channels, num_heatmaps, num_pafs) take different paths
+    through the graph — num_channels = 96: stand-alone depthwise + GEMM for the cpm trunk (the fused kernel takes 64 | 128 |
+    256 | 512 outputs), padded K, the two-GEMM head pair — so one non-default shape of each kind is compared with the oracle
+    on every tapped layer and on the stage outputs."""
+    sd = synth.make_state_dict(1, seed=11, num_channels=C, num_heatmaps=NH, num_pafs=NP)
+    x = net_input(2, 64, 96, seed=410)
+    taps = {}
+    ref = net_ref.forward(sd, torch.from_numpy(x), 1, taps)
+    net = PoseEstimationWithMobileNet(num_refinement_stages=1, num_channels=C, num_heatmaps=NH, num_pafs=NP)
+    load_state(net, {"state_dict": sd})
+    net.eval().cuda()
+    eng = net.engine
+    checked = 0
+    for info in eng.layers():
+        nm = info["name"]
+        key = nm[:-3] if nm.endswith(".pw") and nm.startswith("model.") else (nm if nm in taps else ("cpm" if nm == "cpm.conv" else None))
+        if key is None or key not in taps:
+            continue
+        got = eng.debug_layer_output(x, info["index"])
+        r = taps[key].numpy()
+        assert got.shape == r.shape, nm
+        assert np.abs(got - r).max() <= NET_TOL * max(1.0, float(np.abs(r).max())), nm
+        checked += 1
+    assert checked >= 14
+    outs = net(x)
+    assert [o.shape[1] for o in outs] == [NH, NP, NH, NP]
+    for g, r in zip(outs, ref):
+        assert np.abs(g - r.numpy()).max() <= NET_TOL * max(1.0, float(r.abs().max()))
