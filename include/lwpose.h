@@ -89,7 +89,10 @@ int lwp_weights_blob_import(lwp_handle h, const void* src_device, size_t bytes);
  *      N x {num_heatmaps | num_pafs} x h x w float32 in the order [heat0, paf0, heat1, paf1, ...].
  *      Any H, W >= 8: the map size is that of three stride-2 convs, h = ((H-1)/2+1 -> ... ) (the reference pads to
  *      the stride, val.py:36-49, but does not require it).
- *      Runs on the handle's stream and synchronises it before returning when out_mem is host. */
+ *      Runs on the handle's stream and synchronises it before returning when out_mem is host.
+ *      Size limit: the kernels address an activation tensor with 32-bit byte offsets (buffer loads), so every intermediate
+ *      tensor of a call must stay below 2 GiB — at 368 x 656 that is N <= 128 (fp32) / 256 (bf16); larger batches return
+ *      LWP_ERR_HIP instead of computing (split them into several calls). */
 int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int H, int W,
                 float* const* outs, int out_mem);
 
