@@ -967,3 +967,24 @@ def test_fp32_non_default_channel_counts_match_the_oracle(C, NH, NP):
     assert [o.shape[1] for o in outs] == [NH, NP, NH, NP]
     for g, r in zip(outs, ref):
         assert np.abs(g - r.numpy()).max() <= NET_TOL * max(1.0, float(r.abs().max()))
+
+
+@pytest.mark.gpu
+def test_batch_beyond_the_2gib_tensor_limit_fails_loudly_and_leaves_the_engine_usable():
+    """include/lwpose.h (lwp_forward): the kernels address an activation tensor with 32-bit byte offsets, so a call whose
+    intermediate tensors reach 2 GiB must return an error — not compute garbage or fault.  140 frames of 368 x 656 in fp32:
+    the second block's input (140 x 184 x 328 x 64 floats = 2.16 GB) is over the limit.  The same engine then runs a normal
+    batch correctly."""
+    sd = synth.make_state_dict(1, seed=1)
+    net = PoseEstimationWithMobileNet(num_refinement_stages=1)
+    load_state(net, {"state_dict": sd})
+    net.eval().cuda()
+    x_big = torch.zeros((140, 3, 368, 656), dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError):
+        net(x_big)
+    del x_big
+    torch.cuda.empty_cache()
+    x = net_input(2, 64, 96, seed=100)
+    ref = net_ref.forward(sd, torch.from_numpy(x), 1)
+    for g, r in zip(net(x), ref):
+        assert np.abs(g - r.numpy()).max() <= NET_TOL * max(1.0, float(r.abs().max()))
