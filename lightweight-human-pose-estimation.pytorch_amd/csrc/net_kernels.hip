@@ -491,8 +491,12 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(G
     const int n0 = tile_n * BN;
 
     // per-thread staging assignment: chunk id -> (row, 16-B column)
+    // both operand streams are buffer loads (wave-uniform descriptor, one 32-bit byte offset per lane; a tap outside the image
+    // reads offset 2^31 >= num_records and comes back as zeros)
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)(M * p.in_ld * 4), 0x00020000);   // host: < 2^31 bytes
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
     int a_row[A_PER], a_col[A_PER], a_y[A_PER], a_x[A_PER];
-    int64_t a_base[A_PER];
+    unsigned a_base[A_PER];
     bool a_ok[A_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
@@ -504,14 +508,14 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(G
         const int64_t mm = a_ok[i] ? m : 0;
         a_x[i] = (int)(mm % p.W);
         a_y[i] = (int)((mm / p.W) % p.H);
-        a_base[i] = mm * p.in_ld + a_col[i];
+        a_base[i] = (unsigned)(mm * p.in_ld + a_col[i]) * 4u;        // bytes
     }
     int b_off[B_PER], b_lds[B_PER];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
         const int ch = t + i * GT;
         const int row = ch / (BK / 4), col = (ch % (BK / 4)) * 4;
-        b_off[i] = row * p.cin_pad + col;
+        b_off[i] = (row * p.cin_pad + col) * 4;                      // bytes
         b_lds[i] = row * LDS_LD + col;
     }
 
@@ -528,19 +532,17 @@ __global__ void __launch_bounds__((BM / 32) * (BN / 32) * KS * 64) gemm_kernel(G
         const int c0 = (step - tap * ksteps_per_tap) * BK;
         int dy = 0, dx = 0;
         if (KSZ == 3) { dy = (tap / 3 - 1) * p.dil; dx = (tap % 3 - 1) * p.dil; }
-        const int64_t shift = ((int64_t)dy * p.W + dx) * p.in_ld + c0;
+        const int shift = ((dy * p.W + dx) * p.in_ld + c0) * 4;         // bytes, may be negative
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
             const bool ok = a_ok[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            // taps outside the image read a zero page: the select is on the ADDRESS, so the loaded value goes
-            // to LDS untouched and its s_waitcnt lands after the MFMA block (latency hidden behind compute)
-            const float* src = ok ? p.in + a_base[i] + shift : p.zeros;
-            ar[i] = *(const f32x4*)src;
+            // the select is on the OFFSET, so the loaded value goes to LDS untouched and its s_waitcnt lands after the MFMA block
+            ar[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? a_base[i] + (unsigned)shift : 0x80000000u, 0, 0));
         }
-        const float* wt = p.w + ((int64_t)tap * p.cout_pad + n0) * p.cin_pad + c0;
+        const unsigned woff = (unsigned)__builtin_amdgcn_readfirstlane(((tap * p.cout_pad + n0) * p.cin_pad + c0) * 4);
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) br[i] = *(const f32x4*)(wt + b_off[i]);
+        for (int i = 0; i < B_PER; ++i) br[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], woff, 0));
     };
     auto store_step = [&](int buf, const f32x4* ar, const f32x4* br) {
         float* a = As + buf * BM * LDS_LD;
@@ -623,6 +625,7 @@ template <int BM, int BN, int KS, int KSZ>
 static hipError_t launch_gemm_k(const GemmParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.H * p.W;
     const int64_t tiles = ((M + BM - 1) / BM) * (p.cout_pad / BN);
+    if (M * p.in_ld * 4 >= (1ll << 31)) return hipErrorInvalidValue;         // 32-bit buffer offsets (2 GiB of activations per launch)
     constexpr int NT = (BM / 32) * (BN / 32) * KS * 64;
     size_t lds = (size_t)KS * 2 * (BM + BN) * LDS_LD * sizeof(float);
     const size_t red = (size_t)(KS - 1) * (BM / 32) * (BN / 32) * 16 * 64 * sizeof(float);
