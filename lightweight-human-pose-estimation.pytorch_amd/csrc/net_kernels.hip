@@ -877,6 +877,7 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_ar_kernel(GemmParams
     float* zrow = Ag + (size_t)nb_max * R * LDS_LD;
 
     // ---- stage the group's A data: chunk = (block j, row, 16-byte column)
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((int64_t)M * p.in_ld * 4), 0x00020000);   // host: < 2^31 bytes
     {
         const int t = tid - g * GT;                         // thread within the group
         const int col = (t & 7) * 4;
@@ -896,8 +897,8 @@ __global__ void __launch_bounds__((BN / 32) * KS * 64) gemm_ar_kernel(GemmParams
                     idx = (int64_t)m0 + row;
                 }
                 const bool ok = ch < total && idx >= 0 && idx < M;
-                const float* src = ok ? p.in + idx * p.in_ld + (g + j * KS) * BK + col : p.zeros;
-                tmp[u] = *(const f32x4*)src;
+                // buffer load: rows outside the tensor read offset 2^31 >= num_records and come back as zeros
+                tmp[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? (unsigned)(((int)idx * p.in_ld + (g + j * KS) * BK + col) * 4) : 0x80000000u, 0, 0));
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1032,6 +1033,7 @@ static hipError_t launch_gemm_ar_k(const GemmParams& p, hipStream_t s, bool* fit
     const int64_t M = (int64_t)p.N * p.H * p.W;
     *fits = false;
     if (M >= (1ll << 31) - 64 || !p.wf) return hipSuccess;
+    if (M * p.in_ld * 4 >= (1ll << 31)) return hipSuccess;       // 32-bit buffer offsets: larger inputs take the shared-tile kernel's path (and its check)
     const int kpt = p.cin_pad / BK, nb_max = (kpt + KS - 1) / KS;
     const int R = KSZ == 3 ? 3 * (32 + 2 * p.dil) : 32;
     size_t lds = (size_t)KS * ((size_t)nb_max * R + 1) * LDS_LD * sizeof(float);
