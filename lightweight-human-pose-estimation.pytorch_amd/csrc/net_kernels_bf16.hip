@@ -825,14 +825,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
     // loaded behind it into registers (WCH 16-byte chunks per thread) and replaces block 0 in LDS after the ninth tap.
     const int wtotal = R * 8;                                    // chunks of one 64-channel block (<= WCH * NT: host check)
     bf16x8 wreg[WCH];
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((int64_t)M * p.in_ld * 2), 0x00020000);   // host: < 2^31 bytes
     auto win_load = [&](int m0_, int kb) {
 #pragma unroll
         for (int u = 0; u < WCH; ++u) {
             const int ch = tid + u * NT;
             const int row = ch >> 3, col = (ch & 7) * 8 + kb * HBK;
             const int g = m0_ - halo + row;
-            const __bf16* src = (ch < wtotal && g >= 0 && g < M) ? in + (int64_t)g * p.in_ld + col : (const __bf16*)p.zeros;
-            wreg[u] = *(const bf16x8*)src;
+            // buffer load: rows outside the tensor read offset 2^31 >= num_records and come back as zeros
+            wreg[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(irsrc, (ch < wtotal && g >= 0 && g < M) ? (unsigned)((g * p.in_ld + col) * 2) : 0x80000000u, 0, 0));
         }
     };
     auto win_write = [&]() {
@@ -1099,6 +1100,7 @@ static hipError_t try_gemm_bf16_ar(const GemmParams& p, hipStream_t s, bool* use
     if ((p.out_ld & 7) || (((uintptr_t)p.out) & 15) || (p.in_ld & 7) || (((uintptr_t)p.in) & 15)) return hipSuccess;
     if (p.res && ((p.res_ld & 7) || (((uintptr_t)p.res) & 15))) return hipSuccess;
     if (p.dil * (p.W + 1) > 180) return hipSuccess;           // the kernel's register budget for the window block held in registers
+    if (M * p.in_ld * 2 >= (1ll << 31)) return hipSuccess;     // 32-bit buffer offsets for the window (larger inputs: the shared-tile kernel and its check)
     static const char* fenv = getenv("LWP_GEMMH_AR_FORCE");  // "1": the window-resident kernel at every size (tests)
     if (!(fenv && fenv[0] == '1') && M < 128 * 256) return hipSuccess;      // small problems: the shared-tile kernel's 64 x 64 tiles fill the chip better
     int bm = 0, wm = 0, wn = 0, bd = 0;
