@@ -140,7 +140,7 @@ struct HeadsParams {
 };
 bool heads_bf16_supported(int cin_pad, int hidden, int cout_pad);
 hipError_t launch_heads_bf16(const HeadsParams& p, hipStream_t s);
-// fp32 form for small M (batch 1: 3772 pixels): 16-pixel workgroups, the hidden dimension split over the waves, fixed-order
+// fp32 form for M <= 4096 (batch 1: 3772 pixels): 16-pixel workgroups, the hidden dimension split over the waves, fixed-order
 // reduction of the partial outputs.  Pointers are f32 ([hidden][128], [64][hidden], NHWC f32 window).
 bool heads_f32_supported(int cin_pad, int hidden, int cout_pad, int64_t M);
 hipError_t launch_heads_f32(const HeadsParams& p, hipStream_t s);

@@ -1486,8 +1486,10 @@ __global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
 }
 
 bool heads_f32_supported(int cin_pad, int hidden, int cout_pad, int64_t M) {
-    // every 16-pixel workgroup streams all of W0 and W1 (768 KB for the initial stage): only while the grid is ~2 rounds of the chip
-    return cin_pad == 128 && hidden % 16 == 0 && hidden >= 128 && hidden <= 4096 && cout_pad == 64 && M <= 8192;
+    // every 16-pixel workgroup streams all of W0 and W1 (768 KB for the initial stage): only while the grid is ONE round of the
+    // chip (measured at batch 2, 472 workgroups: 57 us against 27 + 17 for the two GEMMs; batch 1: 29.5 against 18.6 + 9.3 with
+    // two launch floors less)
+    return cin_pad == 128 && hidden % 16 == 0 && hidden >= 128 && hidden <= 4096 && cout_pad == 64 && M <= 4096;
 }
 
 hipError_t launch_heads_f32(const HeadsParams& p, hipStream_t s) {
