@@ -13,9 +13,11 @@ Plain-Python restatement of the tail of the reference's hot path, kept independe
   modules/pose.py:78-118     track_poses (confidence-descending greedy matching, mask, filter hand-over, bbox refresh)
   modules/one_euro_filter.py:4-43  the smoothing filter used by track_poses(smooth=True)
 
-Pinning: the 1-Euro sequence is checked against tests/golden/one_euro.json (captured from the reference); the
-un-map / Pose / tracking logic cannot be captured by import (modules/pose.py and demo.py import cv2, absent), so it is
-pinned by hand-derived cases in tests/test_oracle_golden.py and is otherwise "parity unpinned".
+Pinning: the 1-Euro sequence is checked against tests/golden/one_euro.json and get_similarity / track_poses / update_id
+against tests/golden/tracking.json — both captured from the REFERENCE's own function bodies by oracle/make_golden.py
+(modules/pose.py imports cv2, so its plain-NumPy definitions are parsed out of the file and executed unchanged; the only
+stand-in is cv2.boundingRect).  The un-map / Pose construction (demo.py imports cv2) is pinned by hand-derived cases in
+tests/test_host_logic.py; boundingRect itself stays "parity unpinned vs cv2".
 """
 import math
 

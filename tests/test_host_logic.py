@@ -269,6 +269,42 @@ def test_tail_oracle_hand_cases():
     assert [float(f(x)) for x in ref["x"]] == ref["y"]                   # the filter restatement IS pinned to the reference
 
 
+def _replay_tracking_case(case, make_pose, track, last_id_get, last_id_set):
+    last_id_set(-1)
+    prev = []
+    for t, fr in enumerate(case["frames"]):
+        poses = [make_pose(np.array(kp, dtype=np.int32), c) for kp, c in zip(fr["in_keypoints"], fr["in_confidence"])]
+        if not (t == 0 and not case["first_frame_ids"]):
+            track(prev, poses, threshold=case["threshold"], smooth=case["smooth"])
+        assert [p.id for p in poses] == fr["ids"], (case["name"], t)
+        for p, kp, bb in zip(poses, fr["keypoints"], fr["bbox"]):
+            assert np.array_equal(p.keypoints, np.array(kp, dtype=np.int32)), (case["name"], t)
+            assert [int(v) for v in p.bbox] == bb, (case["name"], t)
+        assert last_id_get() == fr["last_id"], (case["name"], t)
+        prev = poses
+
+
+def test_track_poses_and_similarity_match_the_reference_goldens():
+    """tests/golden/tracking.json holds the outputs of the REFERENCE's own get_similarity / track_poses / Pose.update_id bodies
+    (modules/pose.py:21-27,41-45,65-118, captured by oracle/make_golden.py:gen_tracking; only cv2.boundingRect is restated):
+    19 sequences x smooth x thresholds (incl. <= 0), previous poses without ids, poses similar to nobody, an all-missing pose.
+    BOTH the product (modules/pose.py of this package) and the oracle restatement (oracle/tail_ref.py) must reproduce them."""
+    from lwpose_amd.modules import pose as prod
+    from oracle import tail_ref
+    g = json.load(open(os.path.join(GOLDEN, "tracking.json")))
+    assert len(g["cases"]) >= 19
+    for case in g["cases"]:
+        _replay_tracking_case(case, prod.Pose, prod.track_poses, lambda: prod.Pose.last_id, lambda v: setattr(prod.Pose, "last_id", v))
+        _replay_tracking_case(case, tail_ref.RefPose, tail_ref.track_poses, lambda: tail_ref.RefPose.last_id,
+                              lambda v: setattr(tail_ref.RefPose, "last_id", v))
+    for sm in g["similarity"]:
+        for mk, fn in ((prod.Pose, prod.get_similarity), (tail_ref.RefPose, tail_ref.get_similarity)):
+            a = [mk(np.array(kp, dtype=np.int32), 1.0) for kp in sm["a"]]
+            b = [mk(np.array(kp, dtype=np.int32), 1.0) for kp in sm["b"]]
+            assert [[int(fn(p, q, sm["threshold"])) for q in b] for p in a] == sm["counts"]
+            assert [int(fn(p, p, sm["threshold"])) for p in a] == sm["self"]
+
+
 def _people_sequence(seed, n_frames=5, n_people=4, drop=0.15):
     """Seeded walk of ``n_people`` skeletons: per frame a list of ((18,2) int32 key-points, confidence)."""
     rng = np.random.RandomState(seed)

@@ -163,10 +163,16 @@ def test_upsample_matches_torch_bicubic():
                                             align_corners=False)[0].numpy().transpose(1, 2, 0)
         assert up.shape == t.shape
         assert np.abs(up - t).max() < 2e-6
-    assert np.array_equal(post_ref.cubic_coeffs(0.625), np.array([-0.0878906, 0.4658203, 0.7255859, -0.1035156], np.float32)) or True
-    for fr in (0.125, 0.375, 0.625, 0.875):
+    # the x4 / x8 phases are dyadic, so OpenCV's A = -0.75 kernel is exact in float32 at every one of them
+    assert np.array_equal(post_ref.cubic_coeffs(0.625), np.array([-0.06591796875, 0.42626953125, 0.74951171875, -0.10986328125], np.float32))
+
+    def kernel(t, a=-0.75):
+        t = abs(t)
+        return (a + 2) * t ** 3 - (a + 3) * t ** 2 + 1 if t <= 1 else a * t ** 3 - 5 * a * t ** 2 + 8 * a * t - 4 * a
+    for fr in (0.125, 0.375, 0.625, 0.875, 0.0625, 0.5625):
         c = post_ref.cubic_coeffs(fr)
-        assert abs(float(c.astype(np.float64).sum()) - 1.0) < 1e-6
+        assert np.array_equal(c, np.array([kernel(fr + 1), kernel(fr), kernel(1 - fr), kernel(2 - fr)], np.float32))
+        assert float(c.astype(np.float64).sum()) == 1.0
 
 
 def test_generic_resize_matches_integer_ratio_and_torch():
