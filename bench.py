@@ -52,10 +52,14 @@ KERNEL_NAMES = {"stem": ("stem_kernel",), "fused_dw_pw": ("dwpw_kernel", "dwpw_b
                 "dense_3x3": ("gemm_ar_kernel", "gemm_wp_kernel", "gemm_kernel", "gemm_bf16_kernel", "gemm_bf16_ar_kernel")}
 
 
-def layer_work(layers, N, H, W, elt_bytes=4):
-    """Algorithmic FLOPs (2*MAC) and bytes (in + out + weights at the storage dtype) per kernel family."""
+def layer_work(layers, N, H, W, elt_bytes=4, fused_heads=()):
+    """Algorithmic FLOPs (2*MAC) and bytes (in + out + weights at the storage dtype) per kernel family, and per layer.
+    ``fused_heads``: names of the ".heads.0" layers whose pair runs as ONE kernel — the hidden tensor between the two 1x1
+    convs is then never written or read, so it is not counted."""
     h, w = H, W
     acc = {k: [0.0, 0.0] for k in ("stem", "depthwise", "fused_dw_pw", "gemm_1x1", "dense_3x3")}
+    per_layer = []
+    fused1 = set(n[:-1] + "1" for n in fused_heads)
     for l in layers:
         hi, wi = h, w
         if l["stride"] == 2:
@@ -73,10 +77,13 @@ def layer_work(layers, N, H, W, elt_bytes=4):
             byt = (N * hi * wi * l["cin"] + m_out * l["cout"] + 9 * l["cin"]) * elt_bytes
         else:
             flops = 2.0 * m_out * l["macs_per_pixel"]        # merged heads: zero blocks are not counted
-            byt = (m_out * (l["cin"] + l["cout"]) + l["cin"] * l["cout"] * l["ksize"] ** 2) * elt_bytes
+            a_in = 0 if l["name"] in fused1 else m_out * l["cin"]
+            a_out = 0 if l["name"] in fused_heads else m_out * l["cout"]
+            byt = (a_in + a_out + l["macs_per_pixel"]) * elt_bytes      # weights = MACs per pixel (merged heads: the non-zero blocks)
         acc[k][0] += flops
         acc[k][1] += byt
-    return acc
+        per_layer.append((l["name"], k, flops, byt))
+    return acc, per_layer
 
 
 def rocprof_average_us(family, dtype):
@@ -195,35 +202,46 @@ def parse_args():
 def class_rooflines(eng, x, batch, height, width, dtype, dev_ms):
     """HIP events around EVERY launch of a pass (lwp_profile_launches), grouped into kernel families.  The events add a roughly
     constant gap per launch; the un-instrumented pipeline time (events around 20 whole passes) is the ground truth for the
-    sum, so the per-launch overhead is (sum of per-launch times - pipeline time) / launches and it is removed from every launch."""
+    sum, so the per-launch overhead is (sum of per-launch times - pipeline time) / launches and it is removed from every launch.
+
+    Roof of a family: bound time = max(algorithmic bytes / 8 TB/s, algorithmic FLOPs / MFMA peak of the dtype) over
+    the family's launches; `bound` names the larger term, `achieved` / `peak` are in that roof's unit and frac = achieved / peak
+    = bound time / measured time.  `frac_per_layer_roofs` takes the max per LAYER before summing (a family may mix both kinds)."""
     layers = eng.layers()
     fam = {l["name"]: layer_class(l) for l in layers}
     classes = {k: {"ms": 0.0, "launches": 0} for k in ("stem", "depthwise", "fused_dw_pw", "gemm_1x1", "dense_3x3", "post")}
+    launched = set()
     for name, _, ms in eng.profile_launches(x, reps=10):
         c = classes[fam.get(name, "post")]
         c["ms"] += ms
         c["launches"] += 1
+        launched.add(name)
     n_launch = sum(v["launches"] for v in classes.values())
     ev_overhead_ms = max(sum(v["ms"] for v in classes.values()) - dev_ms, 0.0) / max(n_launch, 1)
     for v in classes.values():
         v["ms_raw"] = v["ms"]
         v["ms"] = max(v["ms"] - ev_overhead_ms * v["launches"], 0.0)
-    work = layer_work(layers, batch, height, width, 4 if dtype == "fp32" else 2)
+    fused_heads = [l["name"] for l in layers if l["name"].endswith(".heads.0") and (l["name"][:-1] + "1") not in launched]
+    work, per_layer = layer_work(layers, batch, height, width, 4 if dtype == "fp32" else 2, fused_heads)
+    pk = MFMA_PEAK_TFLOPS[dtype]
     roofs = {}
     for k, (flops, byt) in work.items():
         ms, nl = classes[k]["ms"], max(classes[k]["launches"], 1)
         if ms <= 0 or flops <= 0:
             continue
-        if k in ("depthwise", "stem"):
+        t_hbm, t_mfma = byt / (HBM_PEAK_GBS * 1e9), flops / (pk * 1e12)            # seconds
+        t_mixed = sum(max(b_ / (HBM_PEAK_GBS * 1e9), f_ / (pk * 1e12)) for _, kk, f_, b_ in per_layer if kk == k)
+        common = {"traffic": None, "avg_launch_us": ms * 1e3 / nl, "launches": nl, "alg_flops_per_launch": flops / nl,
+                  "alg_bytes_per_launch": byt / nl, "flop_per_byte": flops / byt,
+                  "hbm_bound_us_per_launch": t_hbm * 1e6 / nl, "mfma_bound_us_per_launch": t_mfma * 1e6 / nl,
+                  "frac_per_layer_roofs": t_mixed / (ms * 1e-3),
+                  "achieved_GBps": byt / (ms * 1e-3) / 1e9, "achieved_TFLOPs": flops / (ms * 1e-3) / 1e12}
+        if k in ("depthwise", "stem") or t_hbm >= t_mfma:
             ach = byt / (ms * 1e-3) / 1e9
-            roofs[k] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": None, "avg_launch_us": ms * 1e3 / nl, "launches": nl, "alg_bytes_per_launch": byt / nl}
+            roofs[k] = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
         else:
             ach = flops / (ms * 1e-3) / 1e12
-            pk = MFMA_PEAK_TFLOPS[dtype]
-            roofs[k] = {"bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk,
-                        "traffic": None, "avg_launch_us": ms * 1e3 / nl, "launches": nl, "alg_flops_per_launch": flops / nl,
-                        "alg_bytes_per_launch": byt / nl}
+            roofs[k] = dict(common, bound="mfma", achieved=ach, peak=pk, unit="TFLOP/s", frac=ach / pk)
     return roofs, classes, ev_overhead_ms
 
 
@@ -309,6 +327,34 @@ def main():
         eng.infer_poses_async(x, 4, True)
         return eng.fetch_poses()
 
+    def results_equal(a, b):
+        return len(a) == len(b) and all(len(fa) == len(fb) and all(np.array_equal(u, v) for u, v in zip(fa, fb)) for fa, fb in zip(a, b))
+
+    # every replica (engine streams of this rank; on ranks > 0 also engine 0, whose weights came over the broadcast) must give
+    # engine 0's results on this rank's frames bit for bit, and every rank's packed weights must hash alike: a wrong replica
+    # would still print a frames/s line
+    if not rehearsal:
+        ref_res = step()
+        for e in engines[1:]:
+            e.infer_poses_async(x, 4, True)
+            if not results_equal(ref_res, e.fetch_poses()):
+                sys.exit("bench: a replica engine's results differ from engine 0's on the same frames")
+        replica_check = {"engines_checked": len(engines), "identical": True}
+        if world > 1:
+            blob_ = torch.empty(eng.weights_blob_bytes(), dtype=torch.uint8, device=torch.device("cuda", local_rank))
+            eng.export_weights(blob_)
+            b64 = blob_.view(torch.int64) if blob_.numel() % 8 == 0 else blob_.to(torch.int64)
+            digest = torch.stack([b64.sum(), (b64 * torch.arange(1, b64.numel() + 1, device=b64.device)).sum()]).to(red_dev)
+            lo, hi = digest.clone(), digest.clone()
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                sys.exit("bench: the ranks' packed weights differ after the broadcast")
+            replica_check["ranks_with_equal_weight_digest"] = world
+            del blob_, b64
+    else:
+        replica_check = None
+
     _TRACE = [] if os.environ.get("LWP_BENCH_TRACE") else None     # per-iteration host timestamps (diagnostics)
 
     def run_steps(k):
@@ -389,7 +435,7 @@ def main():
                        "parallelism": "dp%d (frames sharded, no data-path collective), %d stream(s) per GPU" % (world, len(engines))},
             "timed_blocks": len(blocks), "block_values": [frames_per_block / b for b in blocks],
             "block_spread": {"min": frames_per_block / max(blocks), "max": frames_per_block / min(blocks)},
-            "pipelined": not args.no_pipeline, "streams": len(engines),
+            "pipelined": not args.no_pipeline, "streams": len(engines), "replica_check": replica_check,
             "poses_per_frame": float(np.mean([len(r[0]) for r in res])),
             "keypoints_per_frame": float(np.mean([len(r[1]) for r in res])),
         }

@@ -214,6 +214,11 @@ int lwp_layer_info(lwp_handle h, int layer_index, char* name, int name_cap, int*
 int lwp_debug_time_layer(lwp_handle h, int layer_index, int N, int H, int W, int iters, float* ms_avg);
 int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int H, int W, int layer_index,
                            float* dst, size_t dst_floats, int out_dims[4]);
+/* name of the kernel variant the LAST lwp_debug_layer_output / lwp_profile_launches pass picked for a layer, e.g.
+ * "dw_tiled<cc=64,s=1,d=1,ph=8>" or "gemm_bf16_ar<256,4,2,3>" ("" before any such pass; the second layer of a fused head
+ * pair reports the pair's kernel).  Lets a test prove that the kernel it means to cover is the one that ran: the launchers
+ * choose by problem size, and the A/B switches (environment, read once per handle in lwp_create) only override that choice. */
+int lwp_debug_layer_variant(lwp_handle h, int layer_index, char* name, int name_cap);
 
 #ifdef __cplusplus
 }

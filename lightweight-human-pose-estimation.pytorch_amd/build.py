@@ -35,19 +35,32 @@ def _stale():
 def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+    # the ablation / experiment defines change the objects without touching a source file: such builds recompile everything
+    special = any(os.environ.get(k) for k in ("LWP_ABLATION", "LWP_DWPW_PF", "LWP_ASM_STAMPS")) or os.path.exists(os.path.join(CSRC, ".special"))
+    objs, jobs = [], []
     for s in SOURCES:
+        src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc] + FLAGS + EXTRA.get(s, []) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        objs.append(obj)
+        if force or special or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([hipcc] + FLAGS + EXTRA.get(s, []) + ["-x", "hip", "-c", src, "-o", obj])
+    marker = os.path.join(CSRC, ".special")
+    if any(os.environ.get(k) for k in ("LWP_ABLATION", "LWP_DWPW_PF", "LWP_ASM_STAMPS")):
+        open(marker, "w").close()                      # the next plain build must recompile too
+    elif os.path.exists(marker):
+        os.remove(marker)
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=min(len(jobs), 5) or 1) as ex:      # one hipcc per translation unit, side by side
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 
 

@@ -18,7 +18,12 @@ struct lwp_context {
     hipStream_t stream = nullptr;
     int dtype = LWP_F32;
     Graph g;
-    bool fuse_heads = true;                // bf16: head pairs as one kernel (LWP_FUSE_HEADS=0 at lwp_create: two GEMMs)
+    bool fuse_heads = true;                // head pairs as one kernel (LWP_FUSE_HEADS=0 at lwp_create: two GEMMs)
+    bool post_on_main = false;             // LWP_POST_STREAM=0 at lwp_create: grouping kernels follow the network on the same stream
+    Tuning tune;                           // kernel-selection A/B switches, read from the environment at lwp_create
+    std::vector<std::string> variants;     // per layer: the kernel variant its last launch picked (debug / profiling entry points only)
+    bool record_variants = false;
+    char variant_buf[kVariantCap] = {0};
     float* d_blob = nullptr;
     float* d_zeros = nullptr;
     bool weights_loaded = false;
@@ -143,6 +148,10 @@ extern "C" int lwp_create(int device_id, int nref, int C, int NH, int NP, int dt
         h->g = build_graph(nref, C, NH, NP, !(fe && fe[0] == '0'), dtype, !(me && me[0] == '0'));
         const char* he = getenv("LWP_FUSE_HEADS");
         h->fuse_heads = !(he && he[0] == '0');
+        const char* pe = getenv("LWP_POST_STREAM");
+        h->post_on_main = pe && pe[0] == '0';
+        h->tune = tuning_from_env();
+        h->variants.assign(h->g.layers.size(), std::string());
     }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete h; return fail(nullptr, LWP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
@@ -384,8 +393,11 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
     int dh, dw;
     level_dims(H, W, g.bufs[l.dst.buf].level, &dh, &dw);
     float* dst = buf_at(h, l.dst);
+    char* vb = h->record_variants ? h->variant_buf : nullptr;
+    if (vb) vb[0] = 0;
     if (l.kind == L_STEM) {
         StemParams p{d_in, wts, bias, dst, N, H, W, dh, dw, h->d_zeros};
+        p.tune = &h->tune; p.variant = vb;
         LAUNCH(h, KC_STEM, h16 ? launch_stem_bf16(p, h->stream) : launch_stem(p, h->stream));
     } else if (l.kind == L_DWPW) {
         int sh, sw;
@@ -398,11 +410,13 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
         p.zeros = h->d_zeros;
         p.N = N; p.Hi = sh; p.Wi = sw; p.Ho = dh; p.Wo = dw; p.C = l.cin; p.cout = l.cout;
         p.stride = l.stride; p.dil = l.dil; p.act_dw = l.act; p.act_pw = l.act2;
+        p.tune = &h->tune; p.variant = vb;
         LAUNCH(h, KC_PW, h16 ? launch_dwpw_bf16(p, h->stream) : launch_dwpw(p, h->stream));
     } else if (l.kind == L_DW) {
         int sh, sw;
         level_dims(H, W, g.bufs[l.src.buf].level, &sh, &sw);
         DwParams p{buf_at(h, l.src), l.src.ld, wts, bias, dst, l.dst.ld, N, sh, sw, dh, dw, l.cin, l.stride, l.dil, l.act};
+        p.tune = &h->tune; p.variant = vb;
         LAUNCH(h, KC_DW, launch_dw(p, h->stream));
     } else {
         GemmParams p;
@@ -417,8 +431,10 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
         p.zeros = h->d_zeros;
         p.N = N; p.H = dh; p.W = dw;
         p.cin_pad = l.cin_pad; p.cout = l.cout; p.cout_pad = l.cout_pad; p.ks = l.ks; p.dil = l.dil; p.act = l.act;
+        p.tune = &h->tune; p.variant = vb;
         LAUNCH(h, l.ks == 1 ? KC_PW : KC_C3, h16 ? launch_gemm_bf16(p, h->stream) : launch_gemm(p, h->stream));
     }
+    if (vb && h->cur_layer >= 0 && h->cur_layer < (int)h->variants.size()) h->variants[h->cur_layer] = vb;
     return LWP_OK;
 }
 
@@ -435,7 +451,7 @@ static bool heads_pair_fusable(lwp_context* h, size_t i, int64_t M) {
     if (a.kind != L_GEMM || b.kind != L_GEMM || a.ks != 1 || b.ks != 1 || a.act != ACT_RELU || b.act != ACT_NONE) return false;
     if (a.res.buf >= 0 || b.res.buf >= 0 || a.out_index >= 0) return false;
     if (b.src.buf != a.dst.buf || b.src.coff != a.dst.coff || b.cin_pad != a.cout_pad || a.cout != a.cout_pad) return false;
-    return h->dtype == LWP_BF16 ? heads_bf16_supported(a.cin_pad, a.cout_pad, b.cout_pad) : heads_f32_supported(a.cin_pad, a.cout_pad, b.cout_pad, M);
+    return h->dtype == LWP_BF16 ? heads_bf16_supported(a.cin_pad, a.cout_pad, b.cout_pad) : heads_f32_supported(a.cin_pad, a.cout_pad, b.cout_pad, M, &h->tune);
 }
 
 static int enqueue_heads_pair(lwp_context* h, const Layer& a, const Layer& b, int N, int H, int W, float* const* d_outs_nchw) {
@@ -450,7 +466,11 @@ static int enqueue_heads_pair(lwp_context* h, const Layer& a, const Layer& b, in
     p.out_nchw2 = (b.out_index2 >= 0 && d_outs_nchw) ? d_outs_nchw[b.out_index2] : nullptr;
     p.out_split = b.out_split;
     p.N = N; p.H = dh; p.W = dw; p.hidden = a.cout_pad; p.cout = b.cout;
+    char* vb = h->record_variants ? h->variant_buf : nullptr;
+    if (vb) vb[0] = 0;
+    p.tune = &h->tune; p.variant = vb;
     LAUNCH(h, KC_PW, h->dtype == LWP_BF16 ? launch_heads_bf16(p, h->stream) : launch_heads_f32(p, h->stream));
+    if (vb && h->cur_layer >= 0 && h->cur_layer + 1 < (int)h->variants.size()) { h->variants[h->cur_layer] = vb; h->variants[h->cur_layer + 1] = vb; }
     return LWP_OK;
 }
 
@@ -465,12 +485,12 @@ static int enqueue_forward(lwp_context* h, const float* d_in, int N, int H, int 
         h->cur_layer = (int)i;
         if ((int)i + 1 < max_layers && heads_pair_fusable(h, i, M3)) {
             int rc = enqueue_heads_pair(h, ls[i], ls[i + 1], N, H, W, d_outs_nchw);
-            if (rc) return rc;
+            if (rc) { h->cur_layer = -1; return rc; }
             ++i;
             continue;
         }
         int rc = enqueue_layer(h, ls[i], d_in, N, H, W, d_outs_nchw);
-        if (rc) return rc;
+        if (rc) { h->cur_layer = -1; return rc; }
     }
     h->cur_layer = -1;
     return LWP_OK;
@@ -546,7 +566,7 @@ extern "C" int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, 
         d_dst = h->d_tmp2;
     }
     MapView v{d_src, (int64_t)C * hs * ws, (int64_t)ws, 1, (int64_t)hs * ws, hs, ws};
-    LAUNCH(h, KC_POST, launch_upsample(v, N, C, ratio, d_dst, h->stream));
+    LAUNCH(h, KC_POST, launch_upsample(v, N, C, ratio, d_dst, h->stream, &h->tune));
     if (dst_mem == LWP_MEM_HOST) {
         HIP_TRY(h, hipMemcpyAsync(dst, d_dst, db, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -611,7 +631,7 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     int* d_yi = (int*)t; t += ny * 4;
     float* d_yw = (float*)t;
     MapView v{d_src, (int64_t)C * hs * ws, (int64_t)ws, 1, (int64_t)hs * ws, hs, ws};
-    LAUNCH(h, KC_POST, launch_upsample(v, N, C, up_ratio, h->d_tmp2, h->stream));
+    LAUNCH(h, KC_POST, launch_upsample(v, N, C, up_ratio, h->d_tmp2, h->stream, &h->tune));
     LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, N, Hs, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, init ? 1 : 0, d_acc, h->stream));
     if (accum_mem == LWP_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(accum, d_acc, ab, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));      // results are complete on return (callers read accum on other streams)
@@ -991,8 +1011,7 @@ extern "C" int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, 
     lwp_context::Slot& sl = h->slots[slot];
     if (sl.pending) return fail(h, LWP_ERR_STATE, "slot still pending: call lwp_pipeline_fetch first");
     if (!h->post_stream) {
-        const char* pe = getenv("LWP_POST_STREAM");      // "0": grouping kernels follow the network on the same stream
-        if (pe && pe[0] == '0') h->post_stream = h->stream;
+        if (h->post_on_main) h->post_stream = h->stream;
         else HIP_TRY(h, hipStreamCreateWithFlags(&h->post_stream, hipStreamNonBlocking));
     }
     if (!sl.ev_maps) {
@@ -1123,7 +1142,9 @@ extern "C" int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int 
     const float* d_in = nullptr;
     rc = stage_input(h, in, LWP_MEM_HOST, (size_t)N * 3 * H * W * sizeof(float), &d_in);
     if (rc) return rc;
+    h->record_variants = true;
     rc = enqueue_forward(h, d_in, N, H, W, nullptr, idx + 1);
+    h->record_variants = false;
     if (rc) return rc;
     const Layer& l = h->g.layers[idx];
     int dh, dw;
@@ -1138,6 +1159,14 @@ extern "C" int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int 
     HIP_TRY(h, hipMemcpyAsync(dst, h->d_tmp, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     out_dims[0] = N; out_dims[1] = l.cout; out_dims[2] = dh; out_dims[3] = dw;
+    return LWP_OK;
+}
+
+extern "C" int lwp_debug_layer_variant(lwp_handle h, int idx, char* name, int name_cap) {
+    if (!h || idx < 0 || idx >= (int)h->g.layers.size() || !name || name_cap <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
+    const std::string& v = h->variants[idx];
+    if ((int)v.size() + 1 > name_cap) return fail(h, LWP_ERR_ARG, "name buffer too small");
+    std::strcpy(name, v.c_str());
     return LWP_OK;
 }
 
@@ -1215,9 +1244,11 @@ extern "C" int lwp_profile_launches(lwp_handle h, const float* in_device, int N,
     size_t nl = 0;
     for (int r = 0; r < reps; ++r) {
         h->profiling = true;
+        h->record_variants = true;
         h->ev_used = 0;
         rc = enqueue_poses(h, in_device, N, H, W, ratio, demo, true);
         h->profiling = false;
+        h->record_variants = false;
         if (rc) return rc;
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         nl = h->ev_used / 2;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,28 @@ struct HostTensor {
 std::string pack_weights(const Graph& g, const std::vector<std::string>& names,
                          const std::vector<HostTensor>& tensors, std::vector<float>& blob);
 
+// ------------------------------------------------------------------ A/B and experiment switches
+// Read from the environment ONCE PER HANDLE (lwp_create) and handed to the launchers through their parameter structs: a
+// function-local `static getenv` would freeze whatever value the first launch of the process happened to see, so a test that
+// toggles a switch between two engines would compare a kernel with itself.  0 / -1 = "not set": the launcher's own heuristic.
+struct Tuning {
+    int stem_ty = 0, stem_wl = -1, stem_debug = 0;                 // LWP_STEM_TY, LWP_STEM_WL, LWP_STEM_DEBUG
+    int dw_tiled = -1, dw_cc = 0, dw_ph = 0;                       // LWP_DW_TILED (0 never | 1 always), LWP_DW_CC, LWP_DW_PH
+    int gemm_wp = -1;                                              // LWP_GEMM_WP (-1 unset, else first digit)
+    bool has_c3 = false, has_pw = false; int c3[3] = {0, 0, 0}, pw[3] = {0, 0, 0};   // LWP_GEMM_C3 / LWP_GEMM_PW = "BM,BN,KS"
+    int dwpw_bm = 0, dwpw_nw = 0, dwpw_debug = 0, dwpwh_debug = 0; // LWP_DWPW_BM, LWP_DWPW_NW, LWP_DWPW_DEBUG, LWP_DWPWH_DEBUG
+    int heads_rm = 0;                                              // LWP_HEADS_RM
+    int gemmh_persist = -1, gemmh_ar_off = 0, gemmh_ar_force = 0, gemmh_debug = 0;   // LWP_GEMMH_PERSIST, LWP_GEMMH_AR=0, LWP_GEMMH_AR_FORCE
+    bool has_gemmh_ar = false, has_gemmh = false; int gemmh_ar[4] = {0, 0, 0, 0}, gemmh[4] = {0, 0, 0, 0};   // LWP_GEMMH_AR / LWP_GEMMH = "a,b,c,d"
+    int upsample_tiled = -1;                                       // LWP_UPSAMPLE_TILED
+    int heads_f32_max_m = 0;                                       // LWP_HEADS_F32_MAXM (tests: force the fused fp32 head pair at larger M)
+};
+Tuning tuning_from_env();
+const Tuning& default_tuning();
+// name of the kernel variant a launcher picked, written when the caller supplies a buffer (debug / profiling entry points)
+constexpr int kVariantCap = 64;
+#define LWP_VARIANT(p, ...) do { if ((p).variant) snprintf((p).variant, lwp::kVariantCap, __VA_ARGS__); } while (0)
+
 // ------------------------------------------------------------------ kernel launch parameters
 struct StemParams {       // (__restrict__: the weights stay scalar loads although the kernel loops over tiles and stores in between)
     const float* __restrict__ in;     // N x 3 x H x W
@@ -89,6 +112,7 @@ struct StemParams {       // (__restrict__: the weights stay scalar loads althou
     float* __restrict__ out;          // N x Ho x Wo x 32
     int N, H, W, Ho, Wo;
     const float* zeros = nullptr;   // >= 16 bytes of zeros (source of out-of-image quads)
+    const Tuning* tune = nullptr; char* variant = nullptr;
 };
 struct DwParams {
     const float* in; int in_ld;      // NHWC, row stride in_ld
@@ -96,6 +120,7 @@ struct DwParams {
     const float* bias;               // [C]
     float* out; int out_ld;
     int N, Hi, Wi, Ho, Wo, C, stride, dil, act;
+    const Tuning* tune = nullptr; char* variant = nullptr;
 };
 struct GemmParams {
     const float* in; int in_ld;      // window start already applied to the pointer
@@ -110,6 +135,7 @@ struct GemmParams {
     const float* zeros;              // >= 16 bytes of zeros (source of out-of-image taps)
     int N, H, W, cin_pad, cout, cout_pad, ks, dil, act;
     int debug = 0;                   // reserved for timing experiments
+    const Tuning* tune = nullptr; char* variant = nullptr;
 };
 struct DwPwParams {
     const float* in; int in_ld;          // depthwise input, NHWC
@@ -121,6 +147,7 @@ struct DwPwParams {
     const float* zeros;
     int N, Hi, Wi, Ho, Wo, C, cout, stride, dil, act_dw, act_pw;
     int debug = 0;                       // ablation switches (LWP_DWPW_DEBUG): 1 skip phase 1, 2 skip B loads, 4 skip MFMAs, 8 no XCD tile remap
+    const Tuning* tune = nullptr; char* variant = nullptr;
 };
 bool dwpw_supported(int C, int cout);
 hipError_t launch_dwpw(const DwPwParams& p, hipStream_t s);
@@ -137,12 +164,13 @@ struct HeadsParams {
     void* out; int out_ld;               // bf16 NHWC window (the concat buffer at the heat/PAF channels)
     float* out_nchw; float* out_nchw2;   // may be null: stage outputs, split at out_split
     int out_split, N, H, W, hidden, cout;
+    const Tuning* tune = nullptr; char* variant = nullptr;
 };
 bool heads_bf16_supported(int cin_pad, int hidden, int cout_pad);
 hipError_t launch_heads_bf16(const HeadsParams& p, hipStream_t s);
 // fp32 form for M <= 4096 (batch 1: 3772 pixels): 16-pixel workgroups, the hidden dimension split over the waves, fixed-order
 // reduction of the partial outputs.  Pointers are f32 ([hidden][128], [64][hidden], NHWC f32 window).
-bool heads_f32_supported(int cin_pad, int hidden, int cout_pad, int64_t M);
+bool heads_f32_supported(int cin_pad, int hidden, int cout_pad, int64_t M, const Tuning* tune = nullptr);
 hipError_t launch_heads_f32(const HeadsParams& p, hipStream_t s);
 hipError_t launch_nchw_from_nhwc_bf16(const void* src, int src_ld, float* dst, int N, int HW, int C, hipStream_t s);
 hipError_t launch_stem(const StemParams& p, hipStream_t s);
@@ -187,7 +215,7 @@ struct PostWorkspace {    // device buffers, sized for (N frames, caps)
 
 hipError_t init_cubic_tables();
 hipError_t launch_reset_ws(int N, PostWorkspace& ws, hipStream_t s);
-hipError_t launch_upsample(const MapView& src, int N, int C, int ratio, float* dst, hipStream_t s);
+hipError_t launch_upsample(const MapView& src, int N, int C, int ratio, float* dst, hipStream_t s, const Tuning* tune = nullptr);
 // threshold + strict 4-neighbour maximum on the (virtually) up-sampled heat-maps; ratio == 1: src is already full-res
 hipError_t launch_find_peaks(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_nms(int N, int ntypes, int Hfull, PostWorkspace& ws, hipStream_t s);

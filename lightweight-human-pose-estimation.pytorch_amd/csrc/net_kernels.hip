@@ -190,15 +190,14 @@ __global__ void __launch_bounds__(ST_TY * ST_TX) stem_kernel(StemParams p) {
 template <bool BF16>
 static hipError_t launch_stem_t(const StemParams& p, hipStream_t s) {
     // tile height: 8 rows when that still gives every CU several workgroups, else 4 or 2 (batch 1: 253 -> 1012 workgroups)
-    static const char* env = getenv("LWP_STEM_TY");
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
     const int tx = (p.Wo + ST_TX - 1) / ST_TX;
     int ty = ((int64_t)tx * ((p.Ho + 7) / 8) * p.N >= 2048) ? 8 : (((int64_t)tx * ((p.Ho + 3) / 4) * p.N >= 2048) ? 4 : 2);
-    if (env) ty = atoi(env);
-    static const char* wlenv = getenv("LWP_STEM_WL");         // "0" | "1": weights through scalar loads | LDS in the small-tile variants (A/B)
-    const bool wl = wlenv ? wlenv[0] == '1' : true;
+    if (T.stem_ty) ty = T.stem_ty;                            // LWP_STEM_TY
+    const bool wl = T.stem_wl != 0;                           // LWP_STEM_WL "0" | "1": weights through scalar loads | LDS in the small-tile variants (A/B)
+    LWP_VARIANT(p, "stem<ty=%d,wl=%d>", ty, (ty == 4 || ty == 2) && wl ? 1 : 0);
 #ifdef LWP_ABLATION
-    static const char* dbg = getenv("LWP_STEM_DEBUG");
-    const int d = dbg ? atoi(dbg) : 0;
+    const int d = T.stem_debug;
 #define ST_DBG(D_) if (ty == 8 && d == D_) { hipLaunchKernelGGL((stem_kernel<BF16, 8, 1, D_>), dim3(tx * ((p.Ho + 7) / 8), p.N), dim3(256), 0, s, p); return hipGetLastError(); }
     ST_DBG(1) ST_DBG(2) ST_DBG(4) ST_DBG(3) ST_DBG(5) ST_DBG(6) ST_DBG(7)
 #undef ST_DBG
@@ -391,28 +390,28 @@ static hipError_t launch_dw_tiled_t(const DwParams& p, hipStream_t s) {
 
 static hipError_t try_dw_tiled(const DwParams& p, hipStream_t s, bool* used) {
     *used = false;
-    static const char* env = getenv("LWP_DW_TILED");         // "0": the per-thread kernel everywhere (A/B)
-    if (env && env[0] == '0') return hipSuccess;
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    if (T.dw_tiled == 0) return hipSuccess;                   // LWP_DW_TILED "0": the per-thread kernel everywhere (A/B)
     const int64_t pixels = (int64_t)p.N * p.Ho * p.Wo;
-    const bool force = env && env[0] == '1';                  // "1": the tiled kernel at every size (tests)
+    const bool force = T.dw_tiled == 1;                       // "1": the tiled kernel at every size (tests)
     if (!force && pixels * p.C < (int64_t)8 * 1024 * 1024) return hipSuccess;       // small maps: the per-thread kernel fills the chip better
     if ((p.stride != 1 && p.stride != 2) || (p.dil != 1 && p.dil != 2) || (p.in_ld & 3) || (p.out_ld & 3)) return hipSuccess;
     if (p.stride == 2 && p.dil == 2) return hipSuccess;
-    static const char* ccenv = getenv("LWP_DW_CC");           // channels per workgroup: "128" | "64" everywhere it applies (experiments)
+    // LWP_DW_CC: channels per workgroup, "128" | "64" everywhere it applies (experiments)
     int cc = p.C % 64 == 0 ? 64 : (p.C % 32 == 0 ? 32 : 0);
     // 128 channels per workgroup (512-byte pieces of the 2-KB pixel rows) measured at batch 32: the 512-channel blocks 4.68 -> 4.90
     // TB/s and model.3 (128 channels, 92 x 164) 4.76 -> 4.91; 256 channels 5.18 -> 4.90, dilation 2 4.16 -> 3.96 and the small
     // 128-channel maps 4.68 -> 3.85 lose with it
     const bool want128 = p.stride == 1 && p.dil == 1 && p.C % 128 == 0 && (p.C >= 512 || (p.C == 128 && pixels * p.C >= (int64_t)32 * 1024 * 1024));
-    if (ccenv ? (atoi(ccenv) == 128 && p.C % 128 == 0 && p.stride == 1) : want128) cc = 128;
+    if (T.dw_cc ? (T.dw_cc == 128 && p.C % 128 == 0 && p.stride == 1) : want128) cc = 128;
     if (!cc) return hipSuccess;
     if (p.C / cc > 65535 || pixels >= (1ll << 31)) return hipSuccess;
     if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4 >= (1ll << 31)) return hipSuccess;       // the tiled kernel addresses its input with 32-bit buffer offsets
     // 16-row patches pay on the first block only (32 channels: 128-byte pixel rows, 30k workgroups): 4.05 -> 5.09 TB/s; the
     // 46 x 82 layers lose with them (cpm.trunk 4.6 -> 3.7 TB/s)
-    static const char* phenv = getenv("LWP_DW_PH");           // patch rows 8 | 16 (experiments)
-    const int ph = phenv ? atoi(phenv) : (cc == 32 ? 16 : 8);
+    const int ph = T.dw_ph ? T.dw_ph : (cc == 32 ? 16 : 8);    // LWP_DW_PH: patch rows 8 | 16 (experiments)
     *used = true;
+    LWP_VARIANT(p, "dw_tiled<cc=%d,s=%d,d=%d,ph=%d>", cc, p.stride, p.dil, ph == 16 && p.stride == 1 ? 16 : 8);
 #define DT_CASE(CC_, S_, D_) if (cc == CC_ && p.stride == S_ && p.dil == D_) return ph == 16 && S_ == 1 ? launch_dw_tiled_t<CC_, S_, D_, 16>(p, s) : launch_dw_tiled_t<CC_, S_, D_, 8>(p, s);
     DT_CASE(64, 1, 1) DT_CASE(64, 1, 2) DT_CASE(64, 2, 1) DT_CASE(32, 1, 1) DT_CASE(32, 1, 2) DT_CASE(32, 2, 1) DT_CASE(128, 1, 1) DT_CASE(128, 1, 2)
 #undef DT_CASE
@@ -429,6 +428,7 @@ hipError_t launch_dw(const DwParams& p, hipStream_t s) {
     const int cg = p.C >> 2;
     // few pixels per thread when the map is small (keep the chip full), more when it is large
     const int64_t pixels = (int64_t)p.N * p.Ho * p.Wo;
+    LWP_VARIANT(p, "dw<px=%d>", pixels * cg >= (int64_t)256 * 256 * 16 ? 2 : 1);
     if (pixels * cg >= (int64_t)256 * 256 * 16) {
         const int64_t total = (int64_t)p.N * p.Ho * ((p.Wo + 1) / 2) * cg;
         hipLaunchKernelGGL(dw_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
@@ -1060,26 +1060,26 @@ static hipError_t launch_gemm_ar_t(const GemmParams& p, hipStream_t s, bool* fit
 }
 
 struct GemmCfg { int bm, bn, ks; };
-static bool parse_cfg(const char* env, GemmCfg* c) {
-    if (!env) return false;
-    return sscanf(env, "%d,%d,%d", &c->bm, &c->bn, &c->ks) == 3;
-}
 
 static hipError_t dispatch_gemm(const GemmParams& p, hipStream_t s, GemmCfg c) {
-    static const char* wp_env = getenv("LWP_GEMM_WP");     // "0": shared-tile kernel for the 32-row configurations too (A/B)
-    if (c.bm == 32 && !wp_env) {                            // A-resident form when the group windows fit in LDS
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    const bool wp_set = T.gemm_wp >= 0;                     // LWP_GEMM_WP "0": shared-tile kernel for the 32-row configurations too (A/B)
+    if (c.bm == 32 && !wp_set) {                            // A-resident form when the group windows fit in LDS
         bool fits = false;
         hipError_t e = hipSuccess;
 #define AR_CASE(BN_, KS_) if (c.bn == BN_ && c.ks == KS_) e = launch_gemm_ar_t<BN_, KS_>(p, s, &fits);
         AR_CASE(64, 1) AR_CASE(64, 2) AR_CASE(64, 4) AR_CASE(32, 4) AR_CASE(32, 8)
 #undef AR_CASE
+        if (fits) LWP_VARIANT(p, "gemm_ar<%d,%d,%d>", c.bn, c.ks, p.ks);
         if (e != hipSuccess || fits) return e;
     }
-    if (c.bm == 32 && !(wp_env && wp_env[0] == '0')) {
+    if (c.bm == 32 && T.gemm_wp != 0) {
+        LWP_VARIANT(p, "gemm_wp<%d,%d,%d>", c.bn, c.ks, p.ks);
 #define WP_CASE(BN_, KS_) if (c.bn == BN_ && c.ks == KS_) return launch_gemm_wp_t<BN_, KS_>(p, s);
         WP_CASE(64, 1) WP_CASE(64, 2) WP_CASE(64, 4) WP_CASE(64, 8) WP_CASE(32, 4) WP_CASE(32, 8)
 #undef WP_CASE
     }
+    LWP_VARIANT(p, "gemm<%d,%d,%d,%d>", c.bm, c.bn, c.ks, p.ks);
 #define GEMM_CASE(BM_, BN_, KS_) \
     if (c.bm == BM_ && c.bn == BN_ && c.ks == KS_) return launch_gemm_t<BM_, BN_, KS_>(p, s);
     GEMM_CASE(32, 64, 1) GEMM_CASE(32, 64, 2) GEMM_CASE(32, 64, 4)
@@ -1096,10 +1096,12 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     const int nsteps = p.ks * p.ks * (p.cin_pad / BK);
     GemmCfg c{64, 64, 1};
     // experiments: LWP_GEMM_C3 / LWP_GEMM_PW = "BM,BN,KS" override the heuristic for dense-3x3 / 1x1 layers
-    static const char* env_c3 = getenv("LWP_GEMM_C3");
-    static const char* env_pw = getenv("LWP_GEMM_PW");
-    GemmCfg o;
-    if (parse_cfg(p.ks == 3 ? env_c3 : env_pw, &o) && (p.cout_pad % o.bn) == 0) return dispatch_gemm(p, s, o);
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    if (p.ks == 3 ? T.has_c3 : T.has_pw) {
+        const int* v = p.ks == 3 ? T.c3 : T.pw;
+        const GemmCfg o{v[0], v[1], v[2]};
+        if (o.bn > 0 && (p.cout_pad % o.bn) == 0) return dispatch_gemm(p, s, o);
+    }
     // heuristic (from tools/gemm_sweep.py on the real layer shapes): with >= ~1.5 waves of 64x64 tiles per CU use
     // them (split K in two while the grid is still short); otherwise 32-row tiles and split K four ways inside
     // the workgroup so that every SIMD of every CU holds waves; narrow heads (N padded to 64) with a long K go
@@ -1349,15 +1351,14 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     if (M / 32 >= 450) bm = 32;
     if (M / 64 >= 900) bm = 64;
     int nw_wg = nw;                                  // waves per workgroup (column split = nw / nw_wg)
-    static const char* env = getenv("LWP_DWPW_BM");
-    static const char* env2 = getenv("LWP_DWPW_NW");
-    if (env) bm = atoi(env);
-    if (env2 && atoi(env2) < nw && nw % atoi(env2) == 0) nw_wg = atoi(env2);
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    if (T.dwpw_bm) bm = T.dwpw_bm;                   // LWP_DWPW_BM
+    if (T.dwpw_nw > 0 && T.dwpw_nw < nw && nw % T.dwpw_nw == 0) nw_wg = T.dwpw_nw;   // LWP_DWPW_NW
     if (bm > 64) bm = 64;
     while (bm > 16 && (size_t)bm * (p.C + 4) * sizeof(float) > 150 * 1024) bm >>= 1;
+    LWP_VARIANT(p, "dwpw<%d,%d>", bm, nw_wg);
 #ifdef LWP_ABLATION
-    static const char* dbg = getenv("LWP_DWPW_DEBUG");
-    const int d = dbg ? atoi(dbg) : 0;
+    const int d = T.dwpw_debug;
 #define DP_DBG(BM_, NW_, D_) if (bm == BM_ && nw_wg == NW_ && d == D_) return launch_dwpw_t<BM_, NW_, D_>(p, s);
 #define DP_DBGS(BM_, NW_) DP_DBG(BM_, NW_, 1) DP_DBG(BM_, NW_, 2) DP_DBG(BM_, NW_, 3) DP_DBG(BM_, NW_, 4) DP_DBG(BM_, NW_, 6) DP_DBG(BM_, NW_, 7) DP_DBG(BM_, NW_, 8)
     DP_DBGS(16, 16) DP_DBGS(16, 8) DP_DBGS(16, 4)
@@ -1485,11 +1486,12 @@ __global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
     }
 }
 
-bool heads_f32_supported(int cin_pad, int hidden, int cout_pad, int64_t M) {
+bool heads_f32_supported(int cin_pad, int hidden, int cout_pad, int64_t M, const Tuning* tune) {
+    const int64_t max_m = (tune && tune->heads_f32_max_m > 0) ? tune->heads_f32_max_m : 4096;     // LWP_HEADS_F32_MAXM (tests)
     // every 16-pixel workgroup streams all of W0 and W1 (768 KB for the initial stage): only while the grid is ONE round of the
     // chip (measured at batch 2, 472 workgroups: 57 us against 27 + 17 for the two GEMMs; batch 1: 29.5 against 18.6 + 9.3 with
     // two launch floors less)
-    return cin_pad == 128 && hidden % 16 == 0 && hidden >= 128 && hidden <= 4096 && cout_pad == 64 && M <= 4096;
+    return cin_pad == 128 && hidden % 16 == 0 && hidden >= 128 && hidden <= 4096 && cout_pad == 64 && M <= max_m;
 }
 
 hipError_t launch_heads_f32(const HeadsParams& p, hipStream_t s) {
@@ -1497,8 +1499,35 @@ hipError_t launch_heads_f32(const HeadsParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.H * p.W;
     if (M * p.in_ld * 4 >= (1ll << 31) || (p.in_ld & 3)) return hipErrorInvalidValue;
     const size_t lds = (size_t)NW * 4 * 64 * 4 * sizeof(float);
+    LWP_VARIANT(p, "heads_f32<%d>", NW);
     hipLaunchKernelGGL(heads_f32_kernel<NW>, dim3((unsigned)((M + 15) / 16)), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------- switches
+const Tuning& default_tuning() { static const Tuning t; return t; }
+Tuning tuning_from_env() {
+    Tuning t;
+    auto geti = [](const char* name, int* dst) { const char* e = getenv(name); if (e && e[0]) *dst = atoi(e); };
+    auto digit = [](const char* name, int* dst) { const char* e = getenv(name); if (e && e[0]) *dst = e[0] - '0'; };
+    geti("LWP_STEM_TY", &t.stem_ty); digit("LWP_STEM_WL", &t.stem_wl); geti("LWP_STEM_DEBUG", &t.stem_debug);
+    digit("LWP_DW_TILED", &t.dw_tiled); geti("LWP_DW_CC", &t.dw_cc); geti("LWP_DW_PH", &t.dw_ph);
+    digit("LWP_GEMM_WP", &t.gemm_wp);
+    if (const char* e = getenv("LWP_GEMM_C3")) t.has_c3 = sscanf(e, "%d,%d,%d", &t.c3[0], &t.c3[1], &t.c3[2]) == 3;
+    if (const char* e = getenv("LWP_GEMM_PW")) t.has_pw = sscanf(e, "%d,%d,%d", &t.pw[0], &t.pw[1], &t.pw[2]) == 3;
+    geti("LWP_DWPW_BM", &t.dwpw_bm); geti("LWP_DWPW_NW", &t.dwpw_nw); geti("LWP_DWPW_DEBUG", &t.dwpw_debug); geti("LWP_DWPWH_DEBUG", &t.dwpwh_debug);
+    geti("LWP_HEADS_RM", &t.heads_rm);
+    digit("LWP_GEMMH_PERSIST", &t.gemmh_persist);
+    if (const char* e = getenv("LWP_GEMMH_AR")) {
+        if (e[0] == '0' && e[1] == 0) t.gemmh_ar_off = 1;
+        else t.has_gemmh_ar = sscanf(e, "%d,%d,%d,%d", &t.gemmh_ar[0], &t.gemmh_ar[1], &t.gemmh_ar[2], &t.gemmh_ar[3]) == 4;
+    }
+    if (const char* e = getenv("LWP_GEMMH_AR_FORCE")) t.gemmh_ar_force = e[0] == '1';
+    geti("LWP_GEMMH_DEBUG", &t.gemmh_debug);
+    if (const char* e = getenv("LWP_GEMMH")) t.has_gemmh = sscanf(e, "%d,%d,%d,%d", &t.gemmh[0], &t.gemmh[1], &t.gemmh[2], &t.gemmh[3]) == 4;
+    digit("LWP_UPSAMPLE_TILED", &t.upsample_tiled);
+    geti("LWP_HEADS_F32_MAXM", &t.heads_f32_max_m);
+    return t;
 }
 
 // ---------------------------------------------------------------------------------------- layout helper

@@ -293,14 +293,14 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
     if (M / 16 >= 2048) bm = 32;
     if (M / 32 >= 2048) bm = 64;
     if (M / 64 >= 1024 && nw >= 8) bm = 128;         // >= 256 output channels: halve the per-workgroup weight stream (measured 3-8 %)
-    static const char* env = getenv("LWP_DWPW_BM");
-    if (env) bm = atoi(env);
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    if (T.dwpw_bm) bm = T.dwpw_bm;                   // LWP_DWPW_BM
     while (bm > 16 && (size_t)bm * ((p.C > p.cout ? p.C : p.cout) + 8) * 2 + (size_t)40 * p.C + 16 > 160 * 1024) bm >>= 1;
     if (bm == 128 && nw < 4) bm = 64;
     // every thread must own a whole 8-channel chunk column: NW*64 threads must be a multiple of C/8 (always true here)
+    LWP_VARIANT(p, "dwpw_bf16<%d,%d,dil=%d>", bm, nw, (nw == 16 && p.dil == 2 && p.stride == 1) ? 2 : 1);
 #ifdef LWP_ABLATION
-    static const char* dbg = getenv("LWP_DWPWH_DEBUG");
-    const int d = dbg ? atoi(dbg) : 0;
+    const int d = T.dwpwh_debug;
 #define DPH_DBG(BM_, NW_, D_) if (bm == BM_ && nw == NW_ && d == D_) return launch_dwpw_bf16_t<BM_, NW_, D_>(p, s);
 #define DPH_DBGS(BM_, NW_) DPH_DBG(BM_, NW_, 1) DPH_DBG(BM_, NW_, 2) DPH_DBG(BM_, NW_, 4) DPH_DBG(BM_, NW_, 6) DPH_DBG(BM_, NW_, 7) DPH_DBG(BM_, NW_, 8) DPH_DBG(BM_, NW_, 14) DPH_DBG(BM_, NW_, 15)
     DPH_DBGS(128, 16) DPH_DBGS(64, 16) DPH_DBGS(32, 16) DPH_DBGS(64, 2) DPH_DBGS(64, 4)
@@ -735,9 +735,10 @@ static hipError_t launch_heads_bf16_t(const HeadsParams& p, hipStream_t s) {
 }
 hipError_t launch_heads_bf16(const HeadsParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.H * p.W;
-    static const char* env = getenv("LWP_HEADS_RM");           // experiments: rows per wave / 32
-    const int rm = env ? atoi(env) : 1;                       // 64 rows per wave (198 VGPRs, 2 waves per SIMD) measured 12-23 % slower
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    const int rm = T.heads_rm ? T.heads_rm : 1;               // LWP_HEADS_RM (experiments): 64 rows per wave (198 VGPRs, 2 waves per SIMD) measured 12-23 % slower
     (void)M;
+    LWP_VARIANT(p, "heads_bf16<%d>", rm == 2 ? 2 : 1);
     return rm == 2 ? launch_heads_bf16_t<2>(p, s) : launch_heads_bf16_t<1>(p, s);
 }
 
@@ -1068,10 +1069,10 @@ static hipError_t launch_gemm_bf16_ar_w(const GemmParams& p, hipStream_t s) {
     hipError_t e = attr.ensure((const void*)gemm_bf16_ar_kernel<BM, WM, WN, KSZ, BD, WCH, DBG>, 160 * 1024);
     if (e != hipSuccess) return e;
     // persistent workgroups: one per CU (or two when two fit), each walking tiles b, b + G, ...
-    static const char* penv = getenv("LWP_GEMMH_PERSIST");   // "0": one workgroup per tile (A/B)
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
     const size_t lds = gemm_bf16_ar_lds(p, BM);
     int64_t grid = tiles;
-    if (!(penv && penv[0] == '0')) {
+    if (T.gemmh_persist != 0) {                              // LWP_GEMMH_PERSIST "0": one workgroup per tile (A/B)
         const int64_t slots = (int64_t)device_cu_count() * (lds <= 80 * 1024 ? 2 : 1);
         if (grid > slots) grid = slots;
     }
@@ -1094,17 +1095,18 @@ static hipError_t launch_gemm_bf16_ar_t(const GemmParams& p, hipStream_t s) {
 static hipError_t try_gemm_bf16_ar(const GemmParams& p, hipStream_t s, bool* used) {
     *used = false;
     const int64_t M = (int64_t)p.N * p.H * p.W;
-    static const char* env = getenv("LWP_GEMMH_AR");         // "0": off; "BM,WM,WN,BD": force a configuration (experiments)
-    if (env && env[0] == '0' && env[1] == 0) return hipSuccess;
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    if (T.gemmh_ar_off) return hipSuccess;                    // LWP_GEMMH_AR "0": off; "BM,WM,WN,BD": force a configuration (experiments)
     if (p.ks != 3 || p.cout_pad % 128 != 0 || p.cin_pad != 128 || (p.cout & 7) || p.out_nchw || p.out_nchw2 || M >= (1ll << 31) - 512) return hipSuccess;
     if ((p.out_ld & 7) || (((uintptr_t)p.out) & 15) || (p.in_ld & 7) || (((uintptr_t)p.in) & 15)) return hipSuccess;
     if (p.res && ((p.res_ld & 7) || (((uintptr_t)p.res) & 15))) return hipSuccess;
     if (p.dil * (p.W + 1) > 180) return hipSuccess;           // the kernel's register budget for the window block held in registers
     if (M * p.in_ld * 2 >= (1ll << 31)) return hipSuccess;     // 32-bit buffer offsets for the window (larger inputs: the shared-tile kernel and its check)
-    static const char* fenv = getenv("LWP_GEMMH_AR_FORCE");  // "1": the window-resident kernel at every size (tests)
-    if (!(fenv && fenv[0] == '1') && M < 128 * 256) return hipSuccess;      // small problems: the shared-tile kernel's 64 x 64 tiles fill the chip better
+    // LWP_GEMMH_AR_FORCE "1": the window-resident kernel at every size (tests)
+    if (!T.gemmh_ar_force && M < 128 * 256) return hipSuccess;      // small problems: the shared-tile kernel's 64 x 64 tiles fill the chip better
     int bm = 0, wm = 0, wn = 0, bd = 0;
-    if (!(env && sscanf(env, "%d,%d,%d,%d", &bm, &wm, &wn, &bd) == 4)) {
+    if (T.has_gemmh_ar) { bm = T.gemmh_ar[0]; wm = T.gemmh_ar[1]; wn = T.gemmh_ar[2]; bd = T.gemmh_ar[3]; }
+    else {
         // (128-row tiles, two workgroups per CU, measured slower at batch 32: 64.9 us against 44.3 for 256 rows, dilation 1)
         // (256 x 128 tiles on FOUR waves of 128 x 64 — 0.75 instead of 1 LDS fragment read per MFMA, one wave per SIMD, 255 VGPRs:
         //  63 us against 46)
@@ -1114,9 +1116,9 @@ static hipError_t try_gemm_bf16_ar(const GemmParams& p, hipStream_t s, bool* use
     }
     if (gemm_bf16_ar_lds(p, bm) > 160 * 1024) return hipSuccess;
     *used = true;
+    LWP_VARIANT(p, "gemm_bf16_ar<%d,%d,%d,%d>", bm, wm, wn, bd);
 #ifdef LWP_ABLATION
-    static const char* dbg = getenv("LWP_GEMMH_DEBUG");
-    const int d = dbg ? atoi(dbg) : 0;
+    const int d = T.gemmh_debug;
 #define GAR_DBG(D_) if (bm == 256 && wm == 4 && wn == 2 && d == D_) return launch_gemm_bf16_ar_t<256, 4, 2, 3, 3, D_>(p, s); \
                     if (bm == 128 && wm == 2 && wn == 2 && d == D_) return launch_gemm_bf16_ar_t<128, 2, 2, 3, 3, D_>(p, s);
     GAR_DBG(1) GAR_DBG(2) GAR_DBG(4) GAR_DBG(8) GAR_DBG(16) GAR_DBG(17) GAR_DBG(21) GAR_DBG(10) GAR_DBG(14) GAR_DBG(15)
@@ -1137,9 +1139,10 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
         if (e != hipSuccess || used) return e;
     }
     // experiments: LWP_GEMMH = "BM,BN,RM,RN"
-    static const char* env = getenv("LWP_GEMMH");
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
     int bm = 0, bn = 0, rm = 0, rn = 0;
-    if (env && sscanf(env, "%d,%d,%d,%d", &bm, &bn, &rm, &rn) == 4 && p.cout_pad % bn == 0) {
+    if (T.has_gemmh && T.gemmh[1] > 0 && p.cout_pad % T.gemmh[1] == 0) {
+        bm = T.gemmh[0]; bn = T.gemmh[1]; rm = T.gemmh[2]; rn = T.gemmh[3];
     } else if (p.cout_pad % 128 == 0 && ((M + 127) / 128) * (p.cout_pad / 128) >= 512) {
         bm = 128; bn = 128; rm = 2; rn = 1;           // 8 waves x (64 x 32): 6-25 % faster than 4 waves x (64 x 64) on every layer at batch 32
     } else if (((M + 127) / 128) * (p.cout_pad / 64) >= 512) {
@@ -1147,6 +1150,7 @@ hipError_t launch_gemm_bf16(const GemmParams& p, hipStream_t s) {
     } else {
         bm = 64; bn = 64; rm = 1; rn = 1;             // 4 waves x (32 x 32): small problems
     }
+    LWP_VARIANT(p, "gemm_bf16<%d,%d,%d,%d>", bm, bn, rm, rn);
 #define GH_CASE(BM_, BN_, RM_, RN_) if (bm == BM_ && bn == BN_ && rm == RM_ && rn == RN_) return launch_gemm_bf16_t<BM_, BN_, RM_, RN_>(p, s);
     GH_CASE(128, 128, 2, 2) GH_CASE(128, 64, 2, 1) GH_CASE(64, 64, 1, 1) GH_CASE(256, 128, 2, 2) GH_CASE(128, 128, 2, 1) GH_CASE(128, 128, 1, 1) GH_CASE(128, 64, 1, 1) GH_CASE(256, 128, 2, 1)
 #undef GH_CASE

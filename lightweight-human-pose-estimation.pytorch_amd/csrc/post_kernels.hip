@@ -156,10 +156,10 @@ __global__ void __launch_bounds__(256) upsample_tiled_kernel(MapView src, int C,
         }
     }
 }
-hipError_t launch_upsample(const MapView& src, int N, int C, int ratio, float* dst, hipStream_t s) {
+hipError_t launch_upsample(const MapView& src, int N, int C, int ratio, float* dst, hipStream_t s, const Tuning* tune) {
     const int Hf = src.h * ratio, Wf = src.w * ratio;
-    static const char* env = getenv("LWP_UPSAMPLE_TILED");           // "0": the per-element kernel (A/B)
-    if ((ratio == 4 || ratio == 8) && !(env && env[0] == '0')) {
+    const Tuning& T = tune ? *tune : default_tuning();               // upsample_tiled 0 (LWP_UPSAMPLE_TILED=0): the per-element kernel (A/B)
+    if ((ratio == 4 || ratio == 8) && T.upsample_tiled != 0) {
         const int LH = UTY / ratio + 4, LW = UTX / ratio + 4;
         const size_t lds = (size_t)(LH * LW + LH * UTX) * C * sizeof(float);
         if (lds <= 64 * 1024) {

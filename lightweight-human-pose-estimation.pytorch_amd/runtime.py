@@ -316,6 +316,12 @@ class Engine(object):
         n = dims[0] * dims[1] * dims[2] * dims[3]
         return buf[:n].reshape(dims[0], dims[1], dims[2], dims[3]).copy()
 
+    def layer_variant(self, layer_index):
+        """Kernel variant the last debug_layer_output / profile_launches pass picked for a layer ("" before any)."""
+        name = C.create_string_buffer(96)
+        check(lib().lwp_debug_layer_variant(self.h.ptr, layer_index, name, 96), self.h.ptr)
+        return name.value.decode()
+
     def _as_device_input(self, x):
         """Checks shared by every entry point that hands ``data_ptr()`` of a resident frame batch to the library: float32,
         contiguous, (N,3,H,W), on this engine's GPU; work still queued on torch's current stream is waited for (the
