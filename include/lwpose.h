@@ -65,6 +65,15 @@ int lwp_create(int device_id, int num_refinement_stages, int num_channels, int n
 int lwp_destroy(lwp_handle h);
 const char* lwp_last_error(lwp_handle h);
 
+/* ---- stream ordering: the reference's net(tensor_img) runs on torch's CURRENT stream (demo.py:64-68), so a caller never
+ *      synchronises by hand.  The handle computes on its own non-blocking stream; with lwp_set_stream(h, s, 1) every later
+ *      entry point that takes or returns DEVICE memory (a) makes its stream wait — by event, without blocking the host — for
+ *      the work queued on `s` so far (the producers of its inputs and the last users of the buffers it overwrites), and (b) makes
+ *      `s` wait for the results it leaves on the device.  `caller_stream` is a hipStream_t (NULL = the legacy default stream,
+ *      which is torch's default current stream).  enable = 0 restores the initial state: no ordering, the caller synchronises
+ *      (lwp_synchronize) around device-memory hand-overs.  Host-memory results are complete on return in both modes. */
+int lwp_set_stream(lwp_handle h, void* caller_stream, int enable);
+
 /* capacities of the post-processing lists (defaults 2048 / 128 / 4096 / 256); overflow => LWP_ERR_CAPACITY */
 int lwp_set_capacity(lwp_handle h, int max_peaks_per_channel, int max_kpts_per_type,
                      int max_connections_per_limb, int max_pose_entries);
@@ -89,10 +98,12 @@ int lwp_weights_blob_import(lwp_handle h, const void* src_device, size_t bytes);
  *      N x {num_heatmaps | num_pafs} x h x w float32 in the order [heat0, paf0, heat1, paf1, ...].
  *      Any H, W >= 8: the map size is that of three stride-2 convs, h = ((H-1)/2+1 -> ... ) (the reference pads to
  *      the stride, val.py:36-49, but does not require it).
- *      Runs on the handle's stream and synchronises it before returning when out_mem is host.
- *      Size limit: the kernels address an activation tensor with 32-bit byte offsets (buffer loads), so every intermediate
- *      tensor of a call must stay below 2 GiB — at 368 x 656 that is N <= 128 (fp32) / 256 (bf16); larger batches return
- *      LWP_ERR_HIP instead of computing (split them into several calls). */
+ *      Runs on the handle's stream and synchronises it before returning when out_mem is host; device outputs are handed
+ *      to the caller's stream by an event when lwp_set_stream is in effect (else call lwp_synchronize before reading them).
+ *      Any N: the kernels address a tensor with 32-bit byte offsets, so a batch whose tensors would reach 2 GiB (at 368 x 656:
+ *      N > 139 in fp32, N > 278 in bf16) is processed in equal chunks inside the call — same results as separate calls.
+ *      fp32 results depend on the batch size at the 1e-6 level only: kernels (tile shapes, split-K, the fused head pair up to
+ *      4096 pixels) are chosen by problem size, and their summation orders differ. */
 int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int H, int W,
                 float* const* outs, int out_mem);
 
@@ -121,6 +132,11 @@ int lwp_scale_dims(int H, int W, double ratio, int base_height, int stride, int*
 int lwp_preprocess_scaled_u8(lwp_handle h, const unsigned char* imgs, int img_mem, int N, int H, int W, double ratio,
                              int base_height, int stride, const double* pad_value, const double* img_mean, double img_scale,
                              float* out_device);
+/* the same for float32 frames: val.normalize (val.py:30-33) starts with np.array(img, dtype=np.float32), so an image of any
+ * other dtype than uint8 is the float32 case after that cast (done by the caller) */
+int lwp_preprocess_scaled_f32(lwp_handle h, const float* imgs, int img_mem, int N, int H, int W, double ratio,
+                              int base_height, int stride, const double* pad_value, const double* img_mean, double img_scale,
+                              float* out_device);
 
 /* ---- bicubic up-sampling: replaces cv2.resize(map, (0,0), fx=r, fy=r, INTER_CUBIC) on float maps
  *      (demo.py:72,76; val.py:98,105).  src: N x C x h x w (mem);  dst: N x (h*r) x (w*r) x C (mem). */

@@ -17,7 +17,7 @@ EXPORTS = [
     "lwp_infer_poses", "lwp_infer_poses_async", "lwp_fetch_poses", "lwp_time_pipeline", "lwp_profile_classes",
     "lwp_synchronize", "lwp_poses_from_maps", "lwp_layer_count", "lwp_layer_info", "lwp_debug_layer_output",
     "lwp_profile_launches", "lwp_debug_time_layer", "lwp_pipeline_submit", "lwp_pipeline_fetch", "lwp_multiscale_accumulate",
-    "lwp_preprocess_dims", "lwp_preprocess_u8", "lwp_scale_dims", "lwp_preprocess_scaled_u8", "lwp_debug_layer_variant",
+    "lwp_preprocess_dims", "lwp_preprocess_u8", "lwp_scale_dims", "lwp_preprocess_scaled_u8", "lwp_debug_layer_variant", "lwp_set_stream", "lwp_preprocess_scaled_f32",
 ]
 
 
@@ -71,10 +71,12 @@ def lib():
     L.lwp_preprocess_u8.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, vp]
     L.lwp_scale_dims.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int] + [ip] * 5
     L.lwp_preprocess_scaled_u8.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, dp, C.c_double, vp]
+    L.lwp_preprocess_scaled_f32.argtypes = L.lwp_preprocess_scaled_u8.argtypes
     L.lwp_layer_count.argtypes = [vp]
     L.lwp_layer_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int] + [ip] * 6 + [i64p]
     L.lwp_debug_layer_output.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, ip]
     L.lwp_debug_layer_variant.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
+    L.lwp_set_stream.argtypes = [vp, vp, C.c_int]
     for name in EXPORTS:
         if name not in ("lwp_last_error",):
             getattr(L, name).restype = C.c_int

@@ -60,6 +60,11 @@ struct lwp_context {
         bool pending = false;
     } slots[2];
     hipStream_t post_stream = nullptr;
+    // caller-stream ordering (lwp_set_stream): work the caller queued on ITS stream is waited for with an event (no host
+    // block), and the caller's stream is made to wait for the handle's results where they stay on the device
+    hipStream_t caller_stream = nullptr;
+    bool caller_ordered = false;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_copy = nullptr;
     // per-launch profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;
@@ -94,7 +99,38 @@ static int ensure_dev(lwp_context* h, float** p, size_t* have, size_t need) {
     return LWP_OK;
 }
 
-extern "C" int lwp_version(void) { return 100; }
+// caller's stream -> handle's stream: everything the caller has queued so far (producers of our inputs, consumers of the
+// buffers we are about to overwrite) is ordered before our next launch.  No-op unless lwp_set_stream enabled it.
+static int order_in(lwp_context* h) {
+    if (!h->caller_ordered) return LWP_OK;
+    HIP_TRY(h, hipEventRecord(h->ev_in, h->caller_stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_in, 0));
+    return LWP_OK;
+}
+// handle's stream `from` -> caller's stream: what the caller queues next sees our device-side results.  Returns true in
+// *ordered when the hand-over was done with an event (the legacy host synchronisation is then not needed).
+static int order_out(lwp_context* h, hipStream_t from, bool* ordered) {
+    *ordered = false;
+    if (!h->caller_ordered) return LWP_OK;
+    HIP_TRY(h, hipEventRecord(h->ev_out, from));
+    HIP_TRY(h, hipStreamWaitEvent(h->caller_stream, h->ev_out, 0));
+    *ordered = true;
+    return LWP_OK;
+}
+
+extern "C" int lwp_version(void) { return 101; }
+
+extern "C" int lwp_set_stream(lwp_handle h, void* caller_stream, int enable) {
+    if (!h) return LWP_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (enable && !h->ev_in) {
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+    }
+    h->caller_stream = (hipStream_t)caller_stream;
+    h->caller_ordered = enable != 0;
+    return LWP_OK;
+}
 
 extern "C" int lwp_param_count(int nref, int C, int NH, int NP) {
     if (nref < 0 || C <= 0 || NH <= 0 || NP <= 0) return LWP_ERR_ARG;
@@ -208,6 +244,7 @@ extern "C" int lwp_destroy(lwp_handle h) {
     }
     if (h->post_stream && h->post_stream != h->stream) (void)hipStreamDestroy(h->post_stream);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_in, h->ev_out, h->ev_copy}) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return LWP_OK;
@@ -379,6 +416,45 @@ static int prof_end(lwp_context* h) {
         if (rc_) return rc_;                       \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------- batch split
+// The kernels address a tensor with 32-bit byte offsets (buffer loads), so one launch sequence takes at most as many frames
+// as keep EVERY tensor of the pass below 2 GiB.  Larger batches are processed in equal chunks inside the entry points — the
+// reference's forward takes any N (models/with_mobilenet.py:114) and so does this library.
+static int frames_per_pass(lwp_context* h, int N, int H, int W) {
+    size_t per = (size_t)3 * H * W * sizeof(float);
+    for (const BufSpec& b : h->g.bufs) {
+        int bh, bw;
+        level_dims(H, W, b.level, &bh, &bw);
+        per = std::max(per, (size_t)bh * bw * b.channels * (h->dtype == LWP_BF16 ? 2 : 4));
+    }
+    int fh, fw;
+    level_dims(H, W, 3, &fh, &fw);
+    per = std::max(per, (size_t)fh * fw * std::max(h->g.NH, h->g.NP) * sizeof(float));
+    const size_t lim = ((size_t)1 << 31) - 4096;
+    const int64_t nmax = std::max<int64_t>(1, (int64_t)(lim / per));
+    if (N <= nmax) return N;
+    const int64_t chunks = (N + nmax - 1) / nmax;
+    return (int)((N + chunks - 1) / chunks);
+}
+
+// the per-frame arrays of a post-processing workspace, seen from frame f0 on (every kernel indexes them by frame)
+static PostWorkspace ws_frames(const PostWorkspace& w, int f0) {
+    if (f0 == 0) return w;
+    PostWorkspace v = w;
+    const PostCaps& c = w.caps;
+    const size_t f = (size_t)f0;
+    v.N = w.N - f0;
+    v.peak_count += f * 18; v.peak_key += f * 18 * c.max_peaks; v.peak_val += f * 18 * c.max_peaks;
+    v.kpt_count += f * 18; v.kpt_xy += f * 18 * c.max_kpts * 2; v.kpt_score += f * 18 * c.max_kpts;
+    v.conn_count += f * 19; v.conn_ij += f * 19 * c.max_conn; v.conn_ratio += f * 19 * c.max_conn;
+    v.flags += f * 4;
+    v.sel_count += f * 19; v.sel_ij += f * 19 * c.max_kpts; v.sel_r += f * 19 * c.max_kpts;
+    v.sel_sa += f * 19 * c.max_kpts; v.sel_sb += f * 19 * c.max_kpts;
+    v.entries_work += f * c.max_entries * 20; v.entries += f * c.max_entries * 20;
+    v.n_entries += f; v.kpts_out += f * 18 * c.max_kpts * 4;
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------- forward
 // element-addressed window of an activation buffer (f32 or bf16 storage)
 static inline float* buf_at(lwp_context* h, const BufRef& r) {
@@ -517,15 +593,17 @@ extern "C" int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int
     int rc = check_frame_shape(h, N, H, W);
     if (rc) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
-    rc = ensure_activations(h, N, H, W);
+    const int Nc = frames_per_pass(h, N, H, W);          // frames per launch sequence (N unless a tensor would reach 2 GiB)
+    rc = ensure_activations(h, Nc, H, W);
     if (rc) return rc;
+    if (in_mem == LWP_MEM_DEVICE || out_mem == LWP_MEM_DEVICE) { rc = order_in(h); if (rc) return rc; }
     const float* d_in = nullptr;
     rc = stage_input(h, in, in_mem, (size_t)N * 3 * H * W * sizeof(float), &d_in);
     if (rc) return rc;
     const int nout = 2 * (1 + h->g.nref);
     int fh, fw;
     level_dims(H, W, 3, &fh, &fw);               // three stride-2 stages: out = (in - 1) / 2 + 1 each
-    std::vector<float*> d_outs(nout);
+    std::vector<float*> d_outs(nout), d_chunk(nout);
     for (int i = 0; i < nout; ++i) {
         if (!outs[i]) return fail(h, LWP_ERR_ARG, "null output pointer");
         if (out_mem == LWP_MEM_DEVICE) { d_outs[i] = outs[i]; continue; }
@@ -534,14 +612,23 @@ extern "C" int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int
         if (rc) return rc;
         d_outs[i] = h->d_outs[i];
     }
-    rc = enqueue_forward(h, d_in, N, H, W, d_outs.data());
-    if (rc) return rc;
+    for (int f0 = 0; f0 < N; f0 += Nc) {
+        const int n = std::min(Nc, N - f0);
+        for (int i = 0; i < nout; ++i) d_chunk[i] = d_outs[i] + (size_t)f0 * (i % 2 ? h->g.NP : h->g.NH) * fh * fw;
+        if (n != h->cur_N) { rc = ensure_activations(h, n, H, W); if (rc) return rc; }      // ragged last chunk
+        rc = enqueue_forward(h, d_in + (size_t)f0 * 3 * H * W, n, H, W, d_chunk.data());
+        if (rc) return rc;
+    }
     if (out_mem == LWP_MEM_HOST) {
         for (int i = 0; i < nout; ++i) {
             const size_t bytes = (size_t)N * (i % 2 ? h->g.NP : h->g.NH) * fh * fw * sizeof(float);
             HIP_TRY(h, hipMemcpyAsync(outs[i], d_outs[i], bytes, hipMemcpyDeviceToHost, h->stream));
         }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+    } else {
+        bool ordered = false;
+        rc = order_out(h, h->stream, &ordered);          // the caller's stream waits for the outputs; without lwp_set_stream the
+        if (rc) return rc;                               // caller synchronises (lwp_synchronize) before touching them
     }
     return LWP_OK;
 }
@@ -551,6 +638,7 @@ extern "C" int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, 
     if (!h || !src || !dst || N <= 0 || C <= 0 || hs <= 0 || ws <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
     if (ratio != 4 && ratio != 8) return fail(h, LWP_ERR_ARG, "upsample ratio must be 4 or 8");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (src_mem == LWP_MEM_DEVICE || dst_mem == LWP_MEM_DEVICE) { int rc0 = order_in(h); if (rc0) return rc0; }
     const size_t sb = (size_t)N * C * hs * ws * sizeof(float), db = sb * ratio * ratio;
     const float* d_src = src;
     if (src_mem == LWP_MEM_HOST) {
@@ -570,6 +658,10 @@ extern "C" int lwp_upsample(lwp_handle h, const float* src, int src_mem, int N, 
     if (dst_mem == LWP_MEM_HOST) {
         HIP_TRY(h, hipMemcpyAsync(dst, d_dst, db, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+    } else {
+        bool ordered = false;
+        int rc1 = order_out(h, h->stream, &ordered);
+        if (rc1) return rc1;
     }
     return LWP_OK;
 }
@@ -587,6 +679,7 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     const size_t sb = (size_t)N * C * hs * ws * sizeof(float), ub = sb * up_ratio * up_ratio, ab = (size_t)N * dst_h * dst_w * C * sizeof(float);
     const float* d_src = maps;
     int rc;
+    if (maps_mem == LWP_MEM_DEVICE || accum_mem == LWP_MEM_DEVICE) { rc = order_in(h); if (rc) return rc; }
     if (maps_mem == LWP_MEM_HOST) {
         rc = ensure_dev(h, &h->d_tmp, &h->d_tmp_bytes, sb);
         if (rc) return rc;
@@ -634,7 +727,10 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     LAUNCH(h, KC_POST, launch_upsample(v, N, C, up_ratio, h->d_tmp2, h->stream, &h->tune));
     LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, N, Hs, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, init ? 1 : 0, d_acc, h->stream));
     if (accum_mem == LWP_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(accum, d_acc, ab, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));      // results are complete on return (callers read accum on other streams)
+    bool ordered = false;
+    if (accum_mem == LWP_MEM_DEVICE) { rc = order_out(h, h->stream, &ordered); if (rc) return rc; }
+    // without lwp_set_stream the results are complete on return (callers read accum on other streams)
+    if (!ordered) HIP_TRY(h, hipStreamSynchronize(h->stream));
     return LWP_OK;
 }
 
@@ -671,12 +767,16 @@ extern "C" int lwp_preprocess_u8(lwp_handle h, const unsigned char* img, int img
     if (rc) return fail(h, rc, "bad frame / network size");
     if (pad[0] < 0 || pad[1] < 0 || pad[2] < 0 || pad[3] < 0) return fail(h, LWP_ERR_ARG, "negative padding");
     HIP_TRY(h, hipSetDevice(h->device));
+    rc = order_in(h);                                    // device frame produced / output buffer last used on the caller's stream
+    if (rc) return rc;
     const unsigned char* d_src = img;
     if (img_mem == LWP_MEM_HOST) {
         const size_t ib = (size_t)H * W * 3;
         rc = ensure_dev(h, &h->d_img, &h->d_img_bytes, ib);
         if (rc) return rc;
+        if (!h->ev_copy) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
         HIP_TRY(h, hipMemcpyAsync(h->d_img, img, ib, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipEventRecord(h->ev_copy, h->stream));
         d_src = (const unsigned char*)h->d_img;
     }
     const size_t nx = (size_t)dw * 4, ny = (size_t)dh * 4;
@@ -703,7 +803,15 @@ extern "C" int lwp_preprocess_u8(lwp_handle h, const unsigned char* img, int img
     p.scale = img_scale;
     p.out = out_device;
     LAUNCH(h, KC_POST, launch_preprocess_u8(p, h->stream));
-    if (img_mem == LWP_MEM_HOST) HIP_TRY(h, hipStreamSynchronize(h->stream));   // the caller may reuse its frame buffer
+    bool ordered = false;
+    rc = order_out(h, h->stream, &ordered);
+    if (rc) return rc;
+    // the caller may reuse its host frame buffer on return: wait for the COPY only; the kernel's output is stream-ordered
+    // (consumed by this handle's next call, or by the caller's stream after the event hand-over)
+    if (img_mem == LWP_MEM_HOST) {
+        if (ordered) HIP_TRY(h, hipEventSynchronize(h->ev_copy));
+        else HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     return LWP_OK;
 }
 
@@ -730,18 +838,33 @@ extern "C" int lwp_scale_dims(int H, int W, double ratio, int base_height, int s
     return LWP_OK;
 }
 
+static int preprocess_scaled_impl(lwp_handle h, const void* imgs, int elem, int img_mem, int N, int H, int W, double ratio,
+                                  int base_height, int stride, const double* pad_value, const double* img_mean,
+                                  double img_scale, float* out_device);
 extern "C" int lwp_preprocess_scaled_u8(lwp_handle h, const unsigned char* imgs, int img_mem, int N, int H, int W, double ratio,
                                         int base_height, int stride, const double* pad_value, const double* img_mean,
                                         double img_scale, float* out_device) {
+    return preprocess_scaled_impl(h, imgs, 1, img_mem, N, H, W, ratio, base_height, stride, pad_value, img_mean, img_scale, out_device);
+}
+extern "C" int lwp_preprocess_scaled_f32(lwp_handle h, const float* imgs, int img_mem, int N, int H, int W, double ratio,
+                                         int base_height, int stride, const double* pad_value, const double* img_mean,
+                                         double img_scale, float* out_device) {
+    return preprocess_scaled_impl(h, imgs, 4, img_mem, N, H, W, ratio, base_height, stride, pad_value, img_mean, img_scale, out_device);
+}
+static int preprocess_scaled_impl(lwp_handle h, const void* imgs, int elem, int img_mem, int N, int H, int W, double ratio,
+                                  int base_height, int stride, const double* pad_value, const double* img_mean,
+                                  double img_scale, float* out_device) {
     if (!h || !imgs || !pad_value || !img_mean || !out_device || N <= 0) return fail(h, LWP_ERR_ARG, "bad argument");
     int dh, dw, Hp, Wp, pad[4];
     int rc = lwp_scale_dims(H, W, ratio, base_height, stride, &dh, &dw, &Hp, &Wp, pad);
     if (rc) return fail(h, rc, "bad frame size / scale ratio");
     if (pad[0] < 0 || pad[1] < 0 || pad[2] < 0 || pad[3] < 0) return fail(h, LWP_ERR_ARG, "negative padding");
     HIP_TRY(h, hipSetDevice(h->device));
-    const unsigned char* d_src = imgs;
+    rc = order_in(h);
+    if (rc) return rc;
+    const void* d_src = imgs;
     if (img_mem == LWP_MEM_HOST) {
-        const size_t ib = (size_t)N * H * W * 3;
+        const size_t ib = (size_t)N * H * W * 3 * elem;
         if (h->d_imgs_bytes < ib) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             if (h->d_imgs) HIP_TRY(h, hipFree(h->d_imgs));
@@ -749,7 +872,9 @@ extern "C" int lwp_preprocess_scaled_u8(lwp_handle h, const unsigned char* imgs,
             HIP_TRY(h, hipMalloc((void**)&h->d_imgs, ib));
             h->d_imgs_bytes = ib;
         }
+        if (!h->ev_copy) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
         HIP_TRY(h, hipMemcpyAsync(h->d_imgs, imgs, ib, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipEventRecord(h->ev_copy, h->stream));
         d_src = h->d_imgs;
     }
     const size_t nx = (size_t)dw * 4, ny = (size_t)dh * 4;
@@ -776,14 +901,18 @@ extern "C" int lwp_preprocess_scaled_u8(lwp_handle h, const unsigned char* imgs,
     }
     char* t = (char*)d_tabs;
     PreScaleParams p;
-    p.src = d_src; p.N = N; p.Hs = H; p.Ws = W;
+    p.src = d_src; p.src_f32 = elem == 4; p.N = N; p.Hs = H; p.Ws = W;
     p.xi = (const int*)t; p.xw = (const float*)(t + nx * 4); p.yi = (const int*)(t + nx * 8); p.yw = (const float*)(t + nx * 8 + ny * 4);
     p.dh = dh; p.dw = dw; p.top = pad[0]; p.left = pad[1]; p.Hp = Hp; p.Wp = Wp;
     for (int c = 0; c < 3; ++c) { p.mean[c] = img_mean[c]; p.pad_value[c] = (float)pad_value[c]; }
     p.scale = img_scale;
     p.out = out_device;
     LAUNCH(h, KC_POST, launch_preprocess_scaled(p, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));         // out_device is consumed on other streams; host frames may be reused
+    bool ordered = false;
+    rc = order_out(h, h->stream, &ordered);
+    if (rc) return rc;
+    if (!ordered) HIP_TRY(h, hipStreamSynchronize(h->stream));                    // no declared caller stream: complete on return
+    else if (img_mem == LWP_MEM_HOST) HIP_TRY(h, hipEventSynchronize(h->ev_copy));   // host frames may be reused: the copy only
     return LWP_OK;
 }
 
@@ -922,7 +1051,7 @@ extern "C" int lwp_group_keypoints(lwp_handle h, const double* kpts, const int* 
 }
 
 // ---------------------------------------------------------------------------------------------- fused pipeline
-static int enqueue_poses(lwp_context* h, const float* d_in, int N, int H, int W, int ratio, int demo, bool with_post) {
+static int enqueue_poses_chunk(lwp_context* h, const float* d_in, int N, int H, int W, int ratio, int demo, bool with_post, PostWorkspace ws) {
     const Graph& g = h->g;
     int fh, fw;
     level_dims(H, W, 3, &fh, &fw);
@@ -951,11 +1080,24 @@ static int enqueue_poses(lwp_context* h, const float* d_in, int N, int H, int W,
         heat = MapView{cat + g.C, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
         paf = MapView{cat + g.C + g.NH, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
     }
-    LAUNCH(h, KC_POST, launch_find_peaks(heat, N, 18, ratio, h->ws, h->stream));
-    LAUNCH(h, KC_POST, launch_nms(N, 18, fh * ratio, h->ws, h->stream));
-    LAUNCH(h, KC_POST, launch_score_pairs(paf, N, ratio, demo, h->ws, h->stream));
-    LAUNCH(h, KC_POST, launch_match(N, h->ws, h->stream));
-    LAUNCH(h, KC_POST, launch_assemble(N, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_find_peaks(heat, N, 18, ratio, ws, h->stream));
+    LAUNCH(h, KC_POST, launch_nms(N, 18, fh * ratio, ws, h->stream));
+    LAUNCH(h, KC_POST, launch_score_pairs(paf, N, ratio, demo, ws, h->stream));
+    LAUNCH(h, KC_POST, launch_match(N, ws, h->stream));
+    LAUNCH(h, KC_POST, launch_assemble(N, ws, h->stream));
+    return LWP_OK;
+}
+
+// the whole batch, in as many equal launch sequences as keep every tensor below the 2 GiB addressing limit (one for any
+// batch the BASELINE configs use); the results of all frames land in h->ws
+static int enqueue_poses(lwp_context* h, const float* d_in, int N, int H, int W, int ratio, int demo, bool with_post) {
+    const int Nc = frames_per_pass(h, N, H, W);
+    for (int f0 = 0; f0 < N; f0 += Nc) {
+        const int n = std::min(Nc, N - f0);
+        if (n != h->cur_N) { int rc = ensure_activations(h, n, H, W); if (rc) return rc; }
+        int rc = enqueue_poses_chunk(h, d_in + (size_t)f0 * 3 * H * W, n, H, W, ratio, demo, with_post, ws_frames(h->ws, f0));
+        if (rc) return rc;
+    }
     return LWP_OK;
 }
 
@@ -966,7 +1108,7 @@ static int prepare_poses(lwp_context* h, int N, int H, int W, int ratio) {
     if (h->g.NH < 18 || h->g.NP < 38) return fail(h, LWP_ERR_ARG, "pose grouping needs >= 18 heat-maps and >= 38 PAFs");
     if (((int64_t)H / 8 + 1) * ratio > 65535 || ((int64_t)W / 8 + 1) * ratio > 65535) return fail(h, LWP_ERR_ARG, "map too large");
     HIP_TRY(h, hipSetDevice(h->device));
-    rc = ensure_activations(h, N, H, W);
+    rc = ensure_activations(h, frames_per_pass(h, N, H, W), H, W);
     if (rc) return rc;
     return ensure_ws(h, N);
 }
@@ -974,6 +1116,8 @@ static int prepare_poses(lwp_context* h, int N, int H, int W, int ratio) {
 extern "C" int lwp_infer_poses_async(lwp_handle h, const float* in_device, int N, int H, int W, int ratio, int demo) {
     if (!h || !in_device) return fail(h, LWP_ERR_ARG, "null argument");
     int rc = prepare_poses(h, N, H, W, ratio);
+    if (rc) return rc;
+    rc = order_in(h);
     if (rc) return rc;
     h->last_N = N;
     return enqueue_poses(h, in_device, N, H, W, ratio, demo, true);
@@ -991,6 +1135,7 @@ extern "C" int lwp_infer_poses(lwp_handle h, const float* in, int in_mem, int N,
     if (!h || !in || !kpt_counts || !kpts || !entries || !n_entries) return fail(h, LWP_ERR_ARG, "null argument");
     int rc = prepare_poses(h, N, H, W, ratio);
     if (rc) return rc;
+    if (in_mem == LWP_MEM_DEVICE) { rc = order_in(h); if (rc) return rc; }
     const float* d_in = nullptr;
     rc = stage_input(h, in, in_mem, (size_t)N * 3 * H * W * sizeof(float), &d_in);
     if (rc) return rc;
@@ -1018,7 +1163,10 @@ extern "C" int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, 
         HIP_TRY(h, hipEventCreateWithFlags(&sl.ev_maps, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
     }
-    rc = ensure_activations(h, N, H, W);
+    const int Nc = frames_per_pass(h, N, H, W);
+    rc = ensure_activations(h, Nc, H, W);
+    if (rc) return rc;
+    rc = order_in(h);
     if (rc) return rc;
     if (sl.ws.caps.max_peaks != h->caps.max_peaks || sl.ws.caps.max_kpts != h->caps.max_kpts) sl.ws.N = 0;   // (re)allocate lazily
     rc = ensure_ws_obj(h, sl.ws, N, h->post_stream);
@@ -1040,10 +1188,14 @@ extern "C" int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, 
     // network on the main stream: the last stage's heads also write f32 NCHW maps into this slot
     const int nout = 2 * (1 + g.nref);
     std::vector<float*> outs(nout, nullptr);
-    outs[nout - 2] = sl.maps[0];
-    outs[nout - 1] = sl.maps[1];
-    rc = enqueue_forward(h, in_device, N, H, W, outs.data());
-    if (rc) return rc;
+    for (int f0 = 0; f0 < N; f0 += Nc) {             // one launch sequence unless a tensor would reach 2 GiB
+        const int n = std::min(Nc, N - f0);
+        if (n != h->cur_N) { rc = ensure_activations(h, n, H, W); if (rc) return rc; }
+        outs[nout - 2] = sl.maps[0] + (size_t)f0 * g.NH * fh * fw;
+        outs[nout - 1] = sl.maps[1] + (size_t)f0 * g.NP * fh * fw;
+        rc = enqueue_forward(h, in_device + (size_t)f0 * 3 * H * W, n, H, W, outs.data());
+        if (rc) return rc;
+    }
     HIP_TRY(h, hipEventRecord(sl.ev_maps, h->stream));
     // post-processing + result copy on the second stream
     if (h->post_stream != h->stream) HIP_TRY(h, hipStreamWaitEvent(h->post_stream, sl.ev_maps, 0));
@@ -1085,6 +1237,7 @@ extern "C" int lwp_poses_from_maps(lwp_handle h, const float* heat, const float*
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = ensure_ws(h, N);
     if (rc) return rc;
+    if (mem == LWP_MEM_DEVICE) { rc = order_in(h); if (rc) return rc; }
     const size_t hb = (size_t)N * h->g.NH * hs * ws * sizeof(float), pb = (size_t)N * h->g.NP * hs * ws * sizeof(float);
     const float *d_heat = heat, *d_paf = paf;
     if (mem == LWP_MEM_HOST) {

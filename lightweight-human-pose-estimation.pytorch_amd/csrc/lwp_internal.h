@@ -235,7 +235,8 @@ void build_resize_table_u8(int n_src, int n_dst, double inv_scale, std::vector<i
 hipError_t launch_preprocess_u8(const PreprocParams& p, hipStream_t s);
 // N uint8 frames -> normalised float64 image, cubic resize by a ratio (f32 coefficients, f64 sums), pad, NCHW float32 (val.py:84-93)
 struct PreScaleParams {
-    const unsigned char* src; int N, Hs, Ws;         // N x Hs x Ws x 3 uint8
+    const void* src; int N, Hs, Ws;                  // N x Hs x Ws x 3 uint8 (float32 when src_f32)
+    bool src_f32 = false;
     const int *xi, *yi;                              // 4 clamped source indices per destination index
     const float *xw, *yw;                            // 4 float32 cubic coefficients per destination index
     int dh, dw, top, left, Hp, Wp;

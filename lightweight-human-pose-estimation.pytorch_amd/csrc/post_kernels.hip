@@ -9,6 +9,7 @@
 //     fly (find_peaks / score_pairs) — so both routes give the same bits;
 //   * line-integral arithmetic is float64 exactly as NumPy does it (keypoints.py:11-13,104-136).
 #pragma clang fp contract(off)
+#include <type_traits>
 #include "lwp_internal.h"
 
 namespace lwp {
@@ -342,7 +343,9 @@ void build_resize_table_ratio(int n_src, int n_dst, double ratio, std::vector<in
     }
 }
 
+template <bool F32>      // F32: the frames are float32 (any non-uint8 image, cast like normalize's np.array(img, dtype=np.float32))
 __global__ void __launch_bounds__(256) preprocess_scaled_kernel(PreScaleParams p) {
+    typedef typename std::conditional<F32, float, unsigned char>::type src_t;
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, n = blockIdx.z;
     if (x >= p.Wp) return;
     const int yy = y - p.top, xx = x - p.left;
@@ -352,7 +355,7 @@ __global__ void __launch_bounds__(256) preprocess_scaled_kernel(PreScaleParams p
         o[0] = p.pad_value[0]; o[plane] = p.pad_value[1]; o[2 * plane] = p.pad_value[2];
         return;
     }
-    const unsigned char* img = p.src + (int64_t)n * p.Hs * p.Ws * 3;
+    const src_t* img = (const src_t*)p.src + (int64_t)n * p.Hs * p.Ws * 3;
     int xo[4];
     double wx[4];
 #pragma unroll
@@ -360,7 +363,7 @@ __global__ void __launch_bounds__(256) preprocess_scaled_kernel(PreScaleParams p
     double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
-        const unsigned char* row = img + (int64_t)p.yi[yy * 4 + ky] * p.Ws * 3;
+        const src_t* row = img + (int64_t)p.yi[yy * 4 + ky] * p.Ws * 3;
         const double wy = (double)p.yw[yy * 4 + ky];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -378,7 +381,8 @@ __global__ void __launch_bounds__(256) preprocess_scaled_kernel(PreScaleParams p
     o[0] = (float)acc[0]; o[plane] = (float)acc[1]; o[2 * plane] = (float)acc[2];
 }
 hipError_t launch_preprocess_scaled(const PreScaleParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(preprocess_scaled_kernel, dim3((p.Wp + 255) / 256, p.Hp, p.N), dim3(256), 0, s, p);
+    if (p.src_f32) hipLaunchKernelGGL(preprocess_scaled_kernel<true>, dim3((p.Wp + 255) / 256, p.Hp, p.N), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(preprocess_scaled_kernel<false>, dim3((p.Wp + 255) / 256, p.Hp, p.N), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

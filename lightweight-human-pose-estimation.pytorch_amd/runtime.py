@@ -25,6 +25,15 @@ class Engine(object):
         self.device_id = device_id
         self._keep = None
 
+    # ------------------------------------------------------------------ stream ordering
+    def _order(self, device=None):
+        """Order the library's stream against torch's CURRENT stream on this GPU with events (lwp_set_stream): no host block.
+        The reference's net(x) runs on the current stream (demo.py:64-68); this gives device tensors the same semantics —
+        inputs written by queued torch work are waited for, and torch work queued after the call sees the device results."""
+        torch = _torch()
+        st = torch.cuda.current_stream(torch.device("cuda", self.device_id) if device is None else device)
+        check(lib().lwp_set_stream(self.h.ptr, C.c_void_p(st.cuda_stream), 1), self.h.ptr)
+
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict):
         """state_dict: key -> torch tensor / numpy array (float32; num_batches_tracked int64)."""
@@ -86,11 +95,9 @@ class Engine(object):
         outs = [torch.empty(s, dtype=torch.float32, device=t.device) for s in shapes]
         ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
         if on_dev:
-            torch.cuda.current_stream(t.device).synchronize()
+            self._order(t.device)                 # events both ways: the outputs are valid for work queued on torch's current stream
         mem = MEM_DEVICE if on_dev else MEM_HOST
         check(lib().lwp_forward(self.h.ptr, t.data_ptr(), mem, N, H, W, ptrs, mem), self.h.ptr)
-        if on_dev:
-            self.synchronize()
         return [o.numpy() for o in outs] if is_np else outs
 
     def synchronize(self):
@@ -101,7 +108,7 @@ class Engine(object):
         """(N,C,h,w) float32 numpy -> (N, h*r, w*r, C) float32 numpy (cv2.resize INTER_CUBIC, demo.py:72,76)."""
         if getattr(maps_nchw, "is_cuda", False):
             a = maps_nchw.detach().contiguous()
-            _torch().cuda.current_stream(a.device).synchronize()
+            self._order(a.device)
             ptr, mem = a.data_ptr(), MEM_DEVICE
         else:
             a = np.ascontiguousarray(maps_nchw.numpy() if hasattr(maps_nchw, "numpy") else maps_nchw, dtype=np.float32)
@@ -128,7 +135,6 @@ class Engine(object):
             if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
                 raise TypeError("frame must be HxWx3 uint8")
             a = img.contiguous()
-            torch.cuda.current_stream(a.device).synchronize()
             ptr, mem = a.data_ptr(), MEM_DEVICE
         else:
             a = np.ascontiguousarray(img)
@@ -140,9 +146,8 @@ class Engine(object):
         x = torch.empty((1, 3, oh, ow), dtype=torch.float32, device=torch.device("cuda", self.device_id))
         pv = (C.c_double * 3)(*[float(v) for v in pad_value])
         mv = (C.c_double * 3)(*[float(v) for v in img_mean])
+        self._order()                             # x is handed to torch's current stream by event; a host frame may be reused on return
         check(lib().lwp_preprocess_u8(self.h.ptr, ptr, mem, H, W, net_input_height_size, stride, pv, mv, float(img_scale), x.data_ptr()), self.h.ptr)
-        if mem == MEM_DEVICE:
-            self.synchronize()
         return x, scale, pad
 
     @staticmethod
@@ -154,28 +159,30 @@ class Engine(object):
         return v[0].value, v[1].value, v[2].value, v[3].value, [int(a) for a in pad]
 
     def preprocess_scaled_u8(self, imgs, ratio, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1 / 256):
-        """N same-sized uint8 frames (N,H,W,3) or one (H,W,3), numpy or cuda tensor -> (x: N x 3 x H' x W' float32 cuda tensor, pad):
-        normalize + cubic resize by ``ratio`` + pad_width of val.py:84-93 in one kernel."""
+        """N same-sized frames (N,H,W,3) or one (H,W,3), numpy or cuda tensor, uint8 or float32 -> (x: N x 3 x H' x W' float32
+        cuda tensor, pad): normalize + cubic resize by ``ratio`` + pad_width of val.py:84-93 in one kernel."""
         torch = _torch()
         on_dev = getattr(imgs, "is_cuda", False)
         a = imgs.contiguous() if on_dev else np.ascontiguousarray(imgs)
-        if (a.dtype != (torch.uint8 if on_dev else np.uint8)) or len(a.shape) not in (3, 4) or a.shape[-1] != 3:
-            raise TypeError("frames must be (N,)HxWx3 uint8")
+        is_u8 = a.dtype == (torch.uint8 if on_dev else np.uint8)
+        is_f32 = a.dtype == (torch.float32 if on_dev else np.float32)
+        if not (is_u8 or is_f32) or len(a.shape) not in (3, 4) or a.shape[-1] != 3:
+            raise TypeError("frames must be (N,)HxWx3 uint8 or float32")
         shp = tuple(a.shape) if len(a.shape) == 4 else (1,) + tuple(a.shape)
         N, H, W = int(shp[0]), int(shp[1]), int(shp[2])
         _, _, oh, ow, pad = self.scale_dims(H, W, ratio, base_height, stride)
         if on_dev:
             if a.device.index != self.device_id:
                 raise ValueError("frames are on cuda:%d but the engine lives on cuda:%d" % (a.device.index, self.device_id))
-            torch.cuda.current_stream(a.device).synchronize()
             ptr, mem = a.data_ptr(), MEM_DEVICE
         else:
             ptr, mem = a.ctypes.data, MEM_HOST
+        self._order()
         x = torch.empty((N, 3, oh, ow), dtype=torch.float32, device=torch.device("cuda", self.device_id))
         pv = (C.c_double * 3)(*[float(v) for v in pad_value])
         mv = (C.c_double * 3)(*[float(v) for v in img_mean])
-        check(lib().lwp_preprocess_scaled_u8(self.h.ptr, ptr, mem, N, H, W, float(ratio), base_height, stride, pv, mv, float(img_scale),
-                                             x.data_ptr()), self.h.ptr)
+        fn = lib().lwp_preprocess_scaled_u8 if is_u8 else lib().lwp_preprocess_scaled_f32
+        check(fn(self.h.ptr, ptr, mem, N, H, W, float(ratio), base_height, stride, pv, mv, float(img_scale), x.data_ptr()), self.h.ptr)
         return x, pad
 
     def multiscale_accumulate(self, accum, maps, up_ratio, pad, n_scales, init=False):
@@ -188,7 +195,6 @@ class Engine(object):
             return a.ctypes.data, MEM_HOST
         if getattr(maps, "is_cuda", False):
             maps = maps.detach().contiguous()
-            _torch().cuda.current_stream(maps.device).synchronize()
         else:
             maps = np.ascontiguousarray(maps, dtype=np.float32)
         shp = tuple(maps.shape)
@@ -206,6 +212,8 @@ class Engine(object):
             raise TypeError("accum must be a C-contiguous float32 array")
         mp, mm = ptr_mem(maps)
         ap, am = ptr_mem(accum)
+        if mm == MEM_DEVICE or am == MEM_DEVICE:
+            self._order()
         padv = (C.c_int * 4)(*[int(v) for v in pad])
         check(lib().lwp_multiscale_accumulate(self.h.ptr, mp, mm, N, shp[-3], shp[-2], shp[-1], up_ratio, padv, H, W, n_scales, ap, am, 1 if init else 0), self.h.ptr)
         return accum
@@ -266,7 +274,7 @@ class Engine(object):
         N, _, H, W = t.shape
         counts, kpts, ent, ne, kcap, ecap = self._result_buffers(N)
         if t.is_cuda:
-            torch.cuda.current_stream(t.device).synchronize()
+            self._order(t.device)
         check(lib().lwp_infer_poses(self.h.ptr, t.data_ptr(), MEM_DEVICE if t.is_cuda else MEM_HOST, N, H, W, upsample_ratio,
                                     1 if demo else 0, counts.ctypes.data_as(C.POINTER(C.c_int)), kpts.ctypes.data, kcap,
                                     ent.ctypes.data, ecap, ne.ctypes.data_as(C.POINTER(C.c_int))), self.h.ptr)
@@ -278,7 +286,7 @@ class Engine(object):
         lay = {"NCHW": 0, "NHWC": 1}[layout]
         if getattr(heat, "is_cuda", False):
             heat, paf = heat.detach().contiguous(), paf.detach().contiguous()
-            _torch().cuda.current_stream(heat.device).synchronize()
+            self._order(heat.device)
             hp, pp, mem = heat.data_ptr(), paf.data_ptr(), MEM_DEVICE
         else:
             heat = np.ascontiguousarray(heat, dtype=np.float32)
@@ -324,8 +332,8 @@ class Engine(object):
 
     def _as_device_input(self, x):
         """Checks shared by every entry point that hands ``data_ptr()`` of a resident frame batch to the library: float32,
-        contiguous, (N,3,H,W), on this engine's GPU; work still queued on torch's current stream is waited for (the
-        library runs on its own non-blocking stream)."""
+        contiguous, (N,3,H,W), on this engine's GPU; work still queued on torch's current stream is ordered before the
+        library's (own, non-blocking) stream by an event — the host does not wait."""
         torch = _torch()
         if not getattr(x, "is_cuda", False):
             raise TypeError("expected a cuda tensor")
@@ -335,7 +343,7 @@ class Engine(object):
             raise ValueError("input tensor must be contiguous")
         if x.device.index != self.device_id:
             raise ValueError("input is on cuda:%d but the engine lives on cuda:%d" % (x.device.index, self.device_id))
-        torch.cuda.current_stream(x.device).synchronize()
+        self._order(x.device)
         return x
 
     def infer_poses_async(self, x_cuda, upsample_ratio=4, demo=True):

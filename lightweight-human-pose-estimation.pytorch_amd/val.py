@@ -32,10 +32,18 @@ def pad_width(img, stride, pad_value, min_dims):
     return out, pad
 
 
-def _as_u8_frames(imgs):
-    a = np.ascontiguousarray(imgs) if not getattr(imgs, "is_cuda", False) else imgs
-    if (str(a.dtype) not in ("uint8", "torch.uint8")) or len(a.shape) != 4 or a.shape[-1] != 3:
-        raise TypeError("frames must be uint8 (N, H, W, 3) — the multi-scale driver starts from the decoded image (val.py:84)")
+def _as_frames(imgs):
+    """(N, H, W, 3) frames for the device kernels: uint8 stays uint8; any other dtype is cast to float32, which is what the
+    reference's normalize does first (np.array(img, dtype=np.float32), val.py:31)."""
+    if getattr(imgs, "is_cuda", False):
+        import torch
+        a = imgs if imgs.dtype in (torch.uint8, torch.float32) else imgs.to(torch.float32)
+    else:
+        a = np.ascontiguousarray(imgs)
+        if a.dtype != np.uint8:
+            a = np.ascontiguousarray(a, dtype=np.float32)
+    if len(a.shape) != 4 or a.shape[-1] != 3:
+        raise TypeError("frames must be (N, H, W, 3)")
     return a
 
 
@@ -49,9 +57,10 @@ def infer(net, img, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(
 
 
 def scaled_inputs(net, imgs, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
-    """Image side of val.py:84-93 for a batch of same-sized uint8 frames (numpy or cuda tensor, N x H x W x 3), on the device:
+    """Image side of val.py:84-93 for a batch of same-sized frames (numpy or cuda tensor, N x H x W x 3; uint8, or any other
+    dtype through float32 like the reference's normalize), on the device:
     per scale the float32 (N,3,H',W') network input (cuda tensor) and its pad [top, left, bottom, right]."""
-    imgs = _as_u8_frames(imgs)
+    imgs = _as_frames(imgs)
     height = int(imgs.shape[1])
     return [net.engine.preprocess_scaled_u8(imgs, scale * base_height / float(height), base_height, stride, pad_value, img_mean, img_scale)
             for scale in scales]
@@ -75,7 +84,7 @@ def accumulate_scales(net, inputs, height, width, stride):
 
 def infer_batch(net, imgs, scales, base_height, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1/256):
     """``infer`` (val.py:81-110) for N same-sized uint8 frames at once; returns cuda tensors (N,H,W,19), (N,H,W,38)."""
-    imgs = _as_u8_frames(np.stack(list(imgs)) if isinstance(imgs, (list, tuple)) else imgs)
+    imgs = _as_frames(np.stack(list(imgs)) if isinstance(imgs, (list, tuple)) else imgs)
     inputs = scaled_inputs(net, imgs, scales, base_height, stride, pad_value, img_mean, img_scale)
     return accumulate_scales(net, inputs, int(imgs.shape[1]), int(imgs.shape[2]), stride)
 

@@ -835,6 +835,17 @@ def test_coco_detections_loop_vs_oracle():
         for kp, sc in zip(kps, scores):
             want.append({"image_id": int(s["file_name"][:-4]), "category_id": 1, "keypoints": [float(v) for v in kp], "score": float(sc)})
     assert len(want) >= 2 and got == want
+    # the multi-scale branch (val.py:118: scales [0.5, 1.0, 1.5, 2.0]) of the same loop
+    got_ms = coco_detections(net, samples[:1], multiscale=True, base_height=184)
+    h, p = infer(net, samples[0]["img"], [0.5, 1.0, 1.5, 2.0], 184, 8)
+    total, by_type = 0, []
+    for k in range(18):
+        total += post_ref.extract_keypoints(h[:, :, k], by_type, total)
+    ent, allk = post_ref.group_keypoints(by_type, p, demo=False)
+    kps, scores = convert_to_coco_format(ent, allk)
+    want_ms = [{"image_id": int(samples[0]["file_name"][:-4]), "category_id": 1, "keypoints": [float(v) for v in kp], "score": float(sc)}
+               for kp, sc in zip(kps, scores)]
+    assert got_ms == want_ms
 
 
 # ------------------------------------------------------------------------------------------ large-M kernels at small, ragged sizes
@@ -1002,24 +1013,103 @@ def test_fp32_non_default_channel_counts_match_the_oracle(C, NH, NP):
 
 
 @pytest.mark.gpu
-def test_batch_beyond_the_2gib_tensor_limit_fails_loudly_and_leaves_the_engine_usable():
-    """include/lwpose.h (lwp_forward): the kernels address an activation tensor with 32-bit byte offsets, so a call whose
-    intermediate tensors reach 2 GiB must return an error — not compute garbage or fault.  140 frames of 368 x 656 in fp32:
-    the second block's input (140 x 184 x 328 x 64 floats = 2.16 GB) is over the limit.  The same engine then runs a normal
-    batch correctly."""
-    sd = synth.make_state_dict(1, seed=1)
-    net = PoseEstimationWithMobileNet(num_refinement_stages=1)
-    load_state(net, {"state_dict": sd})
-    net.eval().cuda()
-    x_big = torch.zeros((140, 3, 368, 656), dtype=torch.float32, device="cuda")
-    with pytest.raises(RuntimeError):
-        net(x_big)
-    del x_big
+def test_batch_beyond_the_2gib_tensor_limit_is_split_inside_the_call():
+    """The reference's forward takes any N (with_mobilenet.py:114).  The kernels address a tensor with 32-bit byte offsets, so a
+    batch whose tensors reach 2 GiB — 140 frames of 368 x 656 in fp32: the second block's input is 2.16 GB — is processed in
+    equal chunks INSIDE lwp_forward / lwp_infer_poses / lwp_pipeline_submit: stage outputs and poses must equal those of the two
+    explicit 70-frame calls bit for bit, and two of the frames are checked against the oracle."""
+    from lwpose_amd import workload
+    net, sd = workload.build_net(nref=1, seed=1, device=0, dtype="fp32")
+    eng_ = net.engine
+    x = torch.from_numpy(net_input(140, 368, 656, seed=900)).cuda()
+    big = [o.cpu() for o in net(x)]
+    for lo in (0, 70):
+        part = [o.cpu() for o in net(x[lo:lo + 70].contiguous())]
+        for b, q in zip(big, part):
+            assert torch.equal(b[lo:lo + 70], q)
+    ref = net_ref.forward(sd, x[[69, 139]].cpu(), 1)
+    for b, r in zip(big, ref):
+        assert np.abs(b[[69, 139]].numpy() - r.numpy()).max() <= NET_TOL
+    res = eng_.infer_poses(x, 4, demo=True)
+    eng_.pipeline_submit(x, 1, 4, True)
+    res_p = eng_.pipeline_fetch(1)
+    assert len(res) == 140 and sum(len(r[0]) for r in res) >= 280
+    for lo in (0, 70):
+        part = eng_.infer_poses(x[lo:lo + 70].contiguous(), 4, demo=True)
+        for f in range(70):
+            for a, b, c in zip(res[lo + f], part[f], res_p[lo + f]):
+                assert np.array_equal(a, b) and np.array_equal(a, c)
+    for f in (69, 70, 139):
+        ent, allk = _oracle_post(big[-2][f].numpy(), big[-1][f].numpy())
+        assert np.array_equal(res[f][1], allk) and np.array_equal(res[f][0].reshape(-1, 20), ent)
+    del x, big
     torch.cuda.empty_cache()
-    x = net_input(2, 64, 96, seed=100)
-    ref = net_ref.forward(sd, torch.from_numpy(x), 1)
-    for g, r in zip(net(x), ref):
-        assert np.abs(g - r.numpy()).max() <= NET_TOL * max(1.0, float(r.abs().max()))
+
+
+@pytest.mark.gpu
+def test_device_tensors_are_ordered_against_the_callers_stream_without_host_sync():
+    """demo.py:64-68: the reference's net(tensor_img) runs on torch's current stream, so inputs written by queued torch work are
+    seen and later torch work sees the outputs.  lwp_set_stream gives the handle (which computes on its own stream) the same
+    semantics through events: the input below is written on a side stream BEHIND ~tens of ms of queued matmuls, net(x) is
+    called at once (it must not block the host), and the outputs are consumed by torch ops queued on that stream."""
+    import time
+    net, sd = get_net(1, 5)
+    x_np = net_input(2, 184, 328, seed=77)
+    want = net(x_np)                                               # host path: complete on return
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    x_dev = torch.zeros((2, 3, 184, 328), dtype=torch.float32, device="cuda")
+    x_src = torch.from_numpy(x_np).cuda()
+    torch.cuda.synchronize()
+    for trial in range(3):
+        x_dev.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            t0 = time.perf_counter()
+            for _ in range(40):
+                a = (a @ a) * 1e-4                                     # keeps the side stream busy for a while
+            x_dev.copy_(x_src)                                         # the real input arrives last
+            outs = net(x_dev)                                          # must wait for it on the device, not on the host
+            t_call = time.perf_counter() - t0
+            got = [o.clone() for o in outs]                            # torch work queued after the call: sees the results
+            res = net.engine.infer_poses(x_dev, 4, demo=True)          # host results: complete on return
+        side.synchronize()
+        t_all = time.perf_counter() - t0
+        for g, w in zip(got, want):
+            assert np.array_equal(g.cpu().numpy(), w), trial           # computed from the real frame, not from the zeros
+        assert t_call < 0.5 * t_all, (t_call, t_all)                    # the forward call returned while the stream was still busy
+        ref = net.engine.infer_poses(x_np, 4, demo=True)
+        for fa, fb in zip(res, ref):
+            for u, v in zip(fa, fb):
+                assert np.array_equal(u, v)
+    # enable = 0 restores the explicit-synchronisation contract
+    from lwpose_amd._lib import check, lib
+    check(lib().lwp_set_stream(net.engine.h.ptr, None, 0), net.engine.h.ptr)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_reference_default_scale_list_and_float_frames_match_the_oracle_driver():
+    """val.py:115-118: the reference's own multi-scale list is [0.5, 1.0, 1.5, 2.0] (BASELINE config 4 drops 2.0); the 2.0 scale is
+    a 736 x 1312 network input.  One full-size frame, nref 1, against the oracle driver; and a float32 image (any non-uint8 input
+    goes through np.array(img, dtype=np.float32) in val.normalize, val.py:31) through the float32 twin of the image-side kernel."""
+    from lwpose_amd.val import infer
+    from oracle import preproc_ref
+    net, sd = get_net(1, 1)
+    img = synth.make_frames(1, 368, 656, seed0=78)[0]
+    scales = [0.5, 1.0, 1.5, 2.0]
+    got_h, got_p = infer(net, img, scales, 368, 8)
+    ref_h, ref_p = preproc_ref.infer(sd, 1, img, scales, 368, 8)
+    assert got_h.shape == (368, 656, 19) and got_p.shape == (368, 656, 38)
+    assert np.abs(got_h - ref_h).max() <= 2e-3 and np.abs(got_p - ref_p).max() <= 2e-3
+    imgf = img[:184, :328].astype(np.float64) + 0.25                    # not uint8: the reference would cast it to float32
+    got_h, got_p = infer(net, imgf, [0.5, 1.0], 184, 8)
+    ref_h, ref_p = preproc_ref.infer(sd, 1, imgf, [0.5, 1.0], 184, 8)
+    assert np.abs(got_h - ref_h).max() <= 2e-3 and np.abs(got_p - ref_p).max() <= 2e-3
+    x, pad = net.engine.preprocess_scaled_u8(imgf.astype(np.float32), 0.75, 184, 8)       # the image side alone: bit-exact
+    scaled = post_ref.resize_cubic_f64_by_ratio(preproc_ref.normalize(imgf, (128, 128, 128), 1 / 256), 0.75)
+    want, pad_ref = preproc_ref.pad_width(scaled, 8, (0, 0, 0), [184, max(scaled.shape[1], 184)])
+    assert pad == pad_ref and np.array_equal(x[0].cpu().numpy(), np.ascontiguousarray(want.transpose(2, 0, 1), dtype=np.float32))
 
 
 # ------------------------------------------------------------------------------------------ weight replication (dist.py, bench.py streams)
