@@ -60,7 +60,8 @@ def build(force=False, verbose=False):
         subprocess.run(cmd, check=True)
     with ThreadPoolExecutor(max_workers=min(len(jobs), 5) or 1) as ex:      # one hipcc per translation unit, side by side
         list(ex.map(run, jobs))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs)
+    os.replace(LIB + ".tmp", LIB)                      # atomic: a snapshot of the tree never sees a half-written library
     return LIB
 
 

@@ -936,7 +936,7 @@ extern "C" int lwp_extract_keypoints(lwp_handle h, float* heatmap, int H, int W,
     LAUNCH(h, KC_POST, launch_reset_ws(1, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_threshold_inplace(h->d_tmp, (int64_t)H * W, h->stream));
     MapView v{h->d_tmp, 0, (int64_t)W, 1, 0, H, W};
-    LAUNCH(h, KC_POST, launch_find_peaks(v, 1, 1, 1, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_find_peaks(v, 1, 1, 1, h->ws, h->stream, &h->tune));
     LAUNCH(h, KC_POST, launch_nms(1, 1, H, h->ws, h->stream));
     HIP_TRY(h, hipMemcpyAsync(hs, h->d_tmp, bytes, hipMemcpyDeviceToHost, h->stream));
     int* h_xy = (int*)((char*)h->h_stage + bytes);
@@ -1080,7 +1080,7 @@ static int enqueue_poses_chunk(lwp_context* h, const float* d_in, int N, int H, 
         heat = MapView{cat + g.C, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
         paf = MapView{cat + g.C + g.NH, (int64_t)fh * fw * cc, (int64_t)fw * cc, (int64_t)cc, 1, fh, fw};
     }
-    LAUNCH(h, KC_POST, launch_find_peaks(heat, N, 18, ratio, ws, h->stream));
+    LAUNCH(h, KC_POST, launch_find_peaks(heat, N, 18, ratio, ws, h->stream, &h->tune));
     LAUNCH(h, KC_POST, launch_nms(N, 18, fh * ratio, ws, h->stream));
     LAUNCH(h, KC_POST, launch_score_pairs(paf, N, ratio, demo, ws, h->stream));
     LAUNCH(h, KC_POST, launch_match(N, ws, h->stream));
@@ -1202,7 +1202,7 @@ extern "C" int lwp_pipeline_submit(lwp_handle h, const float* in_device, int N, 
     const int64_t hw = (int64_t)fh * fw;
     MapView heat{sl.maps[0], (int64_t)g.NH * hw, (int64_t)fw, 1, hw, fh, fw};
     MapView paf{sl.maps[1], (int64_t)g.NP * hw, (int64_t)fw, 1, hw, fh, fw};
-    HIP_TRY(h, launch_find_peaks(heat, N, 18, ratio, sl.ws, h->post_stream));
+    HIP_TRY(h, launch_find_peaks(heat, N, 18, ratio, sl.ws, h->post_stream, &h->tune));
     HIP_TRY(h, launch_nms(N, 18, fh * ratio, sl.ws, h->post_stream));
     HIP_TRY(h, launch_score_pairs(paf, N, ratio, demo, sl.ws, h->post_stream));
     HIP_TRY(h, launch_match(N, sl.ws, h->post_stream));
@@ -1256,7 +1256,7 @@ extern "C" int lwp_poses_from_maps(lwp_handle h, const float* heat, const float*
         hv.ys = (int64_t)ws * h->g.NH; hv.xs = h->g.NH; hv.cs = 1;
         pv.ys = (int64_t)ws * h->g.NP; pv.xs = h->g.NP; pv.cs = 1;
     }
-    LAUNCH(h, KC_POST, launch_find_peaks(hv, N, 18, ratio, h->ws, h->stream));
+    LAUNCH(h, KC_POST, launch_find_peaks(hv, N, 18, ratio, h->ws, h->stream, &h->tune));
     LAUNCH(h, KC_POST, launch_nms(N, 18, hs * ratio, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_score_pairs(pv, N, ratio, demo, h->ws, h->stream));
     LAUNCH(h, KC_POST, launch_match(N, h->ws, h->stream));

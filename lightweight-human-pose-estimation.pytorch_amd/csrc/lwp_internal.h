@@ -92,10 +92,13 @@ struct Tuning {
     int gemm_wp = -1;                                              // LWP_GEMM_WP (-1 unset, else first digit)
     bool has_c3 = false, has_pw = false; int c3[3] = {0, 0, 0}, pw[3] = {0, 0, 0};   // LWP_GEMM_C3 / LWP_GEMM_PW = "BM,BN,KS"
     int dwpw_bm = 0, dwpw_nw = 0, dwpw_debug = 0, dwpwh_debug = 0; // LWP_DWPW_BM, LWP_DWPW_NW, LWP_DWPW_DEBUG, LWP_DWPWH_DEBUG
+    int dwpw_pp_grid = 0;                                          // LWP_DWPW_PP_GRID (tests: persistent grid size, to walk several rounds at small M)
+    int dwpw_pp = -1;                                              // LWP_DWPW_PP (bf16 two-half-tile fused kernel: 0 off, 1 forced)
     int heads_rm = 0;                                              // LWP_HEADS_RM
     int gemmh_persist = -1, gemmh_ar_off = 0, gemmh_ar_force = 0, gemmh_debug = 0;   // LWP_GEMMH_PERSIST, LWP_GEMMH_AR=0, LWP_GEMMH_AR_FORCE
     bool has_gemmh_ar = false, has_gemmh = false; int gemmh_ar[4] = {0, 0, 0, 0}, gemmh[4] = {0, 0, 0, 0};   // LWP_GEMMH_AR / LWP_GEMMH = "a,b,c,d"
     int upsample_tiled = -1;                                       // LWP_UPSAMPLE_TILED
+    int peak_tile = -1, pair_form = -1;                            // LWP_PEAK_TILE (find_peaks tile 0..3), LWP_PAIR_FORM (score_pairs variant)
     int heads_f32_max_m = 0;                                       // LWP_HEADS_F32_MAXM (tests: force the fused fp32 head pair at larger M)
 };
 Tuning tuning_from_env();
@@ -217,7 +220,7 @@ hipError_t init_cubic_tables();
 hipError_t launch_reset_ws(int N, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_upsample(const MapView& src, int N, int C, int ratio, float* dst, hipStream_t s, const Tuning* tune = nullptr);
 // threshold + strict 4-neighbour maximum on the (virtually) up-sampled heat-maps; ratio == 1: src is already full-res
-hipError_t launch_find_peaks(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s);
+hipError_t launch_find_peaks(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s, const Tuning* tune = nullptr);
 hipError_t launch_nms(int N, int ntypes, int Hfull, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_score_pairs(const MapView& paf, int N, int ratio, int demo, PostWorkspace& ws, hipStream_t s);
 hipError_t launch_match(int N, PostWorkspace& ws, hipStream_t s);

@@ -363,14 +363,17 @@ std::string pack_weights(const Graph& g, const std::vector<std::string>& names, 
             const int nw = l.cout / 32, C_ = l.cin;
             if (g.dtype == LWP_BF16) {
                 // bf16: MFMA 16x16x32 operand order [C/32][cout/32][2 tiles][64 lanes][8]; lane (q = lane>>4, i = lane&15)
-                // holds W[n = 32w + 16t + i][k = 32s + 8q + j], j = 0..7
+                // holds W[n = 32w + 8 (i >> 2) + 4 t + (i & 3)][k = 32s + 8q + j], j = 0..7
                 uint16_t* wh = (uint16_t*)w2p;
                 for (int s = 0; s < C_ / 32; ++s)
                     for (int wv = 0; wv < nw; ++wv)
                         for (int t = 0; t < 2; ++t)
                             for (int lane = 0; lane < 64; ++lane)
                                 for (int j = 0; j < 8; ++j) {
-                                    const int k = 32 * s + 8 * (lane >> 4) + j, n = 32 * wv + 16 * t + (lane & 15);
+                                    // rows of a 32-channel block are permuted: MFMA row i of tile t holds channel 8 (i >> 2) + 4 t + (i & 3),
+                                    // so that a lane's two accumulator tiles are 8 consecutive channels of its pixel (16-byte stores)
+                                    const int i_ = lane & 15;
+                                    const int k = 32 * s + 8 * (lane >> 4) + j, n = 32 * wv + 8 * (i_ >> 2) + 4 * t + (i_ & 3);
                                     wh[((((size_t)(s * nw + wv) * 2 + t) * 64 + lane) * 8) + j] =
                                         f32_to_bf16_rne((float)((double)w2[(size_t)n * C_ + k] * sc2[n]));
                                 }

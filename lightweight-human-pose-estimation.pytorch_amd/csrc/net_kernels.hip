@@ -1201,14 +1201,23 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
         const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4), 0x00020000);
         const int pix_b = p.in_ld * 4, row_b = p.Wi * pix_b;
         auto ldw = [&](unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0)); };
-        for (int grp = tid / cg; grp < BM / PXG; grp += NT / cg) {
+        // pixel coordinates are carried incrementally in 32 bits (the host keeps every tensor below 2^31 bytes): one pair of
+        // divisions per thread and tile instead of three 64-bit ones per pixel group
+        const int M32 = (int)M, Wo = p.Wo, Ho = p.Ho;
+        const int gadv = NT / cg;                        // pixel groups a thread advances per iteration
+        const int adv = gadv * PXG, adv_y = adv / Wo, adv_x = adv - adv_y * Wo;      // wave-uniform
+        int grp = tid / cg;
+        int m = (int)m0 + grp * PXG;
+        int xo, yo, img;
+        {
+            const unsigned q1 = (unsigned)m / (unsigned)Wo;
+            xo = m - (int)q1 * Wo;
+            img = (int)(q1 / (unsigned)Ho);
+            yo = (int)q1 - img * Ho;
+        }
+        for (; grp < BM / PXG; grp += gadv) {
             const int row0 = grp * PXG;
-            const int64_t m = m0 + row0;
-            const bool ok0 = m < M;
-            const int64_t mm = ok0 ? m : 0;
-            const int xo = (int)(mm % p.Wo), yo = (int)((mm / p.Wo) % p.Ho);
-            const int img = (int)(mm / ((int64_t)p.Wo * p.Ho));
-            if (p.stride == 1 && p.dil == 1 && m + PXG <= M && xo + PXG <= p.Wo) {
+            if (p.stride == 1 && p.dil == 1 && m + PXG <= M32 && xo + PXG <= Wo) {
                 const int base = ((img * p.Hi + yo) * p.Wi + xo) * pix_b + c * 4;
                 f32x4 win[3][PXG + 2];
 #pragma unroll
@@ -1230,31 +1239,33 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
                     acc.z = apply_act(acc.z, act_dw); acc.w = apply_act(acc.w, act_dw);
                     *(f32x4*)(At + (row0 + i) * ldA + c) = acc;
                 }
-                continue;
-            }
+            } else {
+                int xi = xo, yi = yo, im = img;
 #pragma unroll
-            for (int i = 0; i < PXG; ++i) {           // general path: borders of the row block, stride 2, dilation 2
-                const int64_t mi = m0 + row0 + i;
-                const bool ok = mi < M;
-                const int64_t mq = ok ? mi : 0;
-                const int xi = (int)(mq % p.Wo), yi = (int)((mq / p.Wo) % p.Ho);
-                const int im = (int)(mq / ((int64_t)p.Wo * p.Ho));
-                const int yc = yi * p.stride, xc = xi * p.stride;
-                const int base = ((im * p.Hi + yc) * p.Wi + xc) * pix_b + c * 4;
-                f32x4 x[9];
+                for (int i = 0; i < PXG; ++i) {           // general path: borders of the row block, stride 2, dilation 2
+                    const bool ok = m + i < M32;
+                    const int yc = yi * p.stride, xc = xi * p.stride;
+                    const int base = ((im * p.Hi + yc) * p.Wi + xc) * pix_b + c * 4;
+                    f32x4 x[9];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
-                    const bool in = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
-                    x[t] = ldw(in ? (unsigned)(base + dy * row_b + dx * pix_b) : 0x80000000u);
+                    for (int t = 0; t < 9; ++t) {
+                        const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
+                        const bool in = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
+                        x[t] = ldw(in ? (unsigned)(base + dy * row_b + dx * pix_b) : 0x80000000u);
+                    }
+                    f32x4 acc = bias;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc += x[t] * wv[t];
+                    acc.x = apply_act(acc.x, act_dw); acc.y = apply_act(acc.y, act_dw);
+                    acc.z = apply_act(acc.z, act_dw); acc.w = apply_act(acc.w, act_dw);
+                    *(f32x4*)(At + (row0 + i) * ldA + c) = acc;
+                    if (++xi == Wo) { xi = 0; if (++yi == Ho) { yi = 0; ++im; } }
                 }
-                f32x4 acc = bias;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc += x[t] * wv[t];
-                acc.x = apply_act(acc.x, act_dw); acc.y = apply_act(acc.y, act_dw);
-                acc.z = apply_act(acc.z, act_dw); acc.w = apply_act(acc.w, act_dw);
-                *(f32x4*)(At + (row0 + i) * ldA + c) = acc;
             }
+            m += adv;
+            xo += adv_x; yo += adv_y;
+            if (xo >= Wo) { xo -= Wo; ++yo; }
+            while (yo >= Ho) { yo -= Ho; ++img; }
         }
     }
     __syncthreads();
@@ -1429,6 +1440,10 @@ __global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
     f32x4 acc2[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // block-diagonal second conv (p.out_split > 0: merged heat / PAF pair): hidden channels < hsplit feed outputs < out_split only
+    const int hsplit = p.out_split > 0 ? p.hidden / 2 : p.hidden;
+    const int t_last_lo = p.out_split > 0 ? (p.out_split + 15) / 16 : 4;     // output tiles [0, t_last_lo) hold outputs of the first block
+    const int t_first_hi = p.out_split > 0 ? p.out_split / 16 : 0;          // output tiles [t_first_hi, 4) hold outputs of the second
     auto one = [&](int k, auto P_) {
         constexpr int P = decltype(P_)::value;
         request(k + 1, w0v[P ^ 1], w1v[P ^ 1], &b0v[P ^ 1]);
@@ -1442,10 +1457,17 @@ __global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
         f32x4 hv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[r] = fmaxf(acc1[r] + b0[r], 0.f);
+        // merged heads: W1 is block-diagonal (heat outputs [0, out_split) read the first half of the hidden vector, PAF outputs the
+        // second), so a hidden tile only feeds the output tiles its block touches: 2 (heat) or 3 (PAF) of the 4 at 19 + 38 channels
+        const int ht = wave + (k < my ? k : 0) * NW;                     // wave-uniform
+        const bool first_half = ht * 16 < hsplit;
+        const int t_lo = first_half ? 0 : t_first_hi, t_hi = first_half ? t_last_lo : 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int t = 0; t < 4; ++t) {
+            if (t < t_lo || t >= t_hi) continue;                         // scalar branch around whole MFMA groups
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[P][t][r], hv[r], acc2[t], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[P][t][r], hv[r], acc2[t], 0, 0, 0);
+        }
     };
     int k = 0;
     for (; k + 2 <= my; k += 2) {
@@ -1516,6 +1538,7 @@ Tuning tuning_from_env() {
     if (const char* e = getenv("LWP_GEMM_C3")) t.has_c3 = sscanf(e, "%d,%d,%d", &t.c3[0], &t.c3[1], &t.c3[2]) == 3;
     if (const char* e = getenv("LWP_GEMM_PW")) t.has_pw = sscanf(e, "%d,%d,%d", &t.pw[0], &t.pw[1], &t.pw[2]) == 3;
     geti("LWP_DWPW_BM", &t.dwpw_bm); geti("LWP_DWPW_NW", &t.dwpw_nw); geti("LWP_DWPW_DEBUG", &t.dwpw_debug); geti("LWP_DWPWH_DEBUG", &t.dwpwh_debug);
+    digit("LWP_DWPW_PP", &t.dwpw_pp); geti("LWP_DWPW_PP_GRID", &t.dwpw_pp_grid);
     geti("LWP_HEADS_RM", &t.heads_rm);
     digit("LWP_GEMMH_PERSIST", &t.gemmh_persist);
     if (const char* e = getenv("LWP_GEMMH_AR")) {
@@ -1526,6 +1549,7 @@ Tuning tuning_from_env() {
     geti("LWP_GEMMH_DEBUG", &t.gemmh_debug);
     if (const char* e = getenv("LWP_GEMMH")) t.has_gemmh = sscanf(e, "%d,%d,%d,%d", &t.gemmh[0], &t.gemmh[1], &t.gemmh[2], &t.gemmh[3]) == 4;
     digit("LWP_UPSAMPLE_TILED", &t.upsample_tiled);
+    digit("LWP_PEAK_TILE", &t.peak_tile); digit("LWP_PAIR_FORM", &t.pair_form);
     geti("LWP_HEADS_F32_MAXM", &t.heads_f32_max_m);
     return t;
 }

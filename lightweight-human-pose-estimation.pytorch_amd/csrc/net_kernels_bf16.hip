@@ -121,13 +121,23 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
                               (__bf16)act_f(a.hi.x, act_dw), (__bf16)act_f(a.hi.y, act_dw), (__bf16)act_f(a.hi.z, act_dw), (__bf16)act_f(a.hi.w, act_dw)};
             *(bf16x8*)(At + row * ldA + c) = o;
         };
-        for (int grp = tid / cg; grp < BM / PXG; grp += NT / cg) {
+        // pixel coordinates are carried incrementally (32-bit; the host keeps every tensor below 2^31 bytes): one pair of
+        // divisions per thread and tile instead of three 64-bit ones per pixel group (they were ~40 % of this phase's VALU work)
+        const int M32 = (int)M, Wo = p.Wo, Ho = p.Ho;
+        const int gadv = NT / cg;                        // pixel groups a thread advances per iteration
+        const int adv = gadv * PXG, adv_y = adv / Wo, adv_x = adv - adv_y * Wo;      // wave-uniform
+        int grp = tid / cg;
+        int m = (int)m0 + grp * PXG;
+        int xo, yo, img;
+        {
+            const unsigned q1 = (unsigned)m / (unsigned)Wo;
+            xo = m - (int)q1 * Wo;
+            img = (int)(q1 / (unsigned)Ho);
+            yo = (int)q1 - img * Ho;
+        }
+        for (; grp < BM / PXG; grp += gadv) {
             const int row0 = grp * PXG;
-            const int64_t m = m0 + row0;
-            const int64_t mm = m < M ? m : 0;
-            const int xo = (int)(mm % p.Wo), yo = (int)((mm / p.Wo) % p.Ho);
-            const int img = (int)(mm / ((int64_t)p.Wo * p.Ho));
-            if (p.stride == 1 && m + PXG <= M && xo + PXG <= p.Wo && p.dil == SDIL) {
+            if (p.stride == 1 && m + PXG <= M32 && xo + PXG <= Wo && p.dil == SDIL) {
                 constexpr int NV = PXG + 2 * SDIL;
                 const int base = ((img * p.Hi + yo) * p.Wi + xo) * pix_b + c * 2;
                 f32x8 a[PXG];
@@ -155,29 +165,31 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
                 }
 #pragma unroll
                 for (int i = 0; i < PXG; ++i) finish(a[i], row0 + i);
-                continue;
-            }
+            } else {
+                int xi = xo, yi = yo, im = img;
 #pragma unroll 1
-            for (int i = 0; i < PXG; ++i) {           // general path: groups that cross an image row or the end of the tensor, stride 2
-                const int64_t mi = m0 + row0 + i;
-                const bool ok = mi < M;
-                const int64_t mq = ok ? mi : 0;
-                const int xi = (int)(mq % p.Wo), yi = (int)((mq / p.Wo) % p.Ho);
-                const int im = (int)(mq / ((int64_t)p.Wo * p.Ho));
-                const int yc = yi * p.stride, xc = xi * p.stride;
-                const int base = ((im * p.Hi + yc) * p.Wi + xc) * pix_b + c * 2;
-                bf16x8 x[9];
+                for (int i = 0; i < PXG; ++i) {           // general path: groups that cross an image row or the end of the tensor, stride 2
+                    const bool ok = m + i < M32;
+                    const int yc = yi * p.stride, xc = xi * p.stride;
+                    const int base = ((im * p.Hi + yc) * p.Wi + xc) * pix_b + c * 2;
+                    bf16x8 x[9];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
-                    const bool inb = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
-                    x[t] = ldw(inb ? (unsigned)(base + dy * row_b + dx * pix_b) : 0x80000000u);
+                    for (int t = 0; t < 9; ++t) {
+                        const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
+                        const bool inb = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
+                        x[t] = ldw(inb ? (unsigned)(base + dy * row_b + dx * pix_b) : 0x80000000u);
+                    }
+                    f32x8 a = wtap(9);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) fma8(a, x[t], wtap(t));
+                    finish(a, row0 + i);
+                    if (++xi == Wo) { xi = 0; if (++yi == Ho) { yi = 0; ++im; } }
                 }
-                f32x8 a = wtap(9);
-#pragma unroll
-                for (int t = 0; t < 9; ++t) fma8(a, x[t], wtap(t));
-                finish(a, row0 + i);
             }
+            m += adv;
+            xo += adv_x; yo += adv_y;
+            if (xo >= Wo) { xo -= Wo; ++yo; }
+            while (yo >= Ho) { yo -= Ho; ++img; }
         }
     }
     __syncthreads();
@@ -225,12 +237,38 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     // itself gives 8 bytes per lane at a 2*out_ld-byte stride, i.e. partial 128-byte lines: 30 us of the 143 us of a 512 -> 512
     // block at batch 32 (ablation), 94 of the 186 us of model.1.
     constexpr int WC = NW * 32;                      // channels of this workgroup
+    if (NW >= 8 ? !(p.debug & 64) : (p.debug & 64) != 0) {
+        // direct form (the wide blocks; LWP_DWPWH_DEBUG bit 64 flips the choice, A/B): the permuted row packing gives a lane 8
+        // consecutive channels of its pixel in its two accumulator tiles -> one 16-byte store per lane and row tile, 64 contiguous
+        // bytes per pixel, no LDS round trip, no barrier.  Measured at batch 32: 512 -> 512 119.1 -> 115.5 us, 256 -> 512 76.2 -> 72.8,
+        // dilation 2 129.6 -> 125.8; the narrow early blocks (64 / 128 outputs: 128-byte pixel rows) lose 1-3 % with it and keep
+        // the LDS-staged form below
+        const int n = blockIdx.y * WC + (tid >> 6) * 32 + 8 * q;
+        const f32x4 b0 = *(const f32x4*)(p.pw_b + n), b1 = *(const f32x4*)(p.pw_b + n + 4);
+#pragma unroll
+        for (int a = 0; a < RT; ++a) {
+            const int64_t m = m0 + a * 16 + i16;
+            f32x4 v0 = acc[a][0] + b0, v1 = acc[a][1] + b1;
+            v0.x = act_f(v0.x, act_pw); v0.y = act_f(v0.y, act_pw); v0.z = act_f(v0.z, act_pw); v0.w = act_f(v0.w, act_pw);
+            v1.x = act_f(v1.x, act_pw); v1.y = act_f(v1.y, act_pw); v1.z = act_f(v1.z, act_pw); v1.w = act_f(v1.w, act_pw);
+            if (m < M) {
+                if (res) {
+                    const bf16x8 r = *(const bf16x8*)(res + m * p.res_ld + n);
+                    v0.x += (float)r[0]; v0.y += (float)r[1]; v0.z += (float)r[2]; v0.w += (float)r[3];
+                    v1.x += (float)r[4]; v1.y += (float)r[5]; v1.z += (float)r[6]; v1.w += (float)r[7];
+                }
+                const bf16x8 o = {(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w, (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
+                *(bf16x8*)(out + m * p.out_ld + n) = o;
+            }
+        }
+        return;
+    }
     constexpr int OLD = WC + 8;                      // staged row stride (elements)
     __bf16* Ot = (__bf16*)dsm_raw;                   // [BM][OLD]
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int nl = (tid >> 6) * 32 + t * 16 + 4 * q;             // channel within the workgroup's window
+        const int nl = (tid >> 6) * 32 + 8 * q + 4 * t;              // channel within the workgroup's window (rows of a 32-channel block are packed permuted: MFMA row 4q + r of tile t <-> channel 8q + 4t + r)
         const int n = blockIdx.y * WC + nl;
         const f32x4 bias = *(const f32x4*)(p.pw_b + n);
 #pragma unroll
@@ -274,6 +312,238 @@ static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------- fused depthwise -> pointwise, two half-tiles in flight
+// The 256- and 512-channel blocks at large M (batch 32).  In dwpw_bf16_kernel a workgroup owns its CU (133 KB tile) and its
+// phases run one after the other: depthwise (VALU + vector-memory bound, ~35 us of a 512 -> 512 layer), K loop (matrix pipe +
+// LDS, ~28 us), write-out (~25 us).  Here ONE persistent 16-wave workgroup holds TWO 64-pixel half-tiles: wave group g (8 waves,
+// two per SIMD) alternates between the depthwise role on its next half-tile and the K-loop + store role on its current one,
+// half a period apart from the other group — so on every SIMD two waves issue VALU / vector-memory work while the other two
+// issue MFMAs and LDS reads (separate pipes run concurrently across waves), and the stores of one half-tile travel while the
+// other is being multiplied.  One workgroup barrier per slot; the depthwise weights are shared by both groups.
+// Epilogue without LDS: the pointwise weights are packed with a row permutation inside every 32-channel block (MFMA row 4q + r
+// of tile e <-> channel 8q + 4e + r), so a lane ends up with 8 CONSECUTIVE channels of a pixel in two accumulator tiles: one
+// 16-byte store per lane, 64 contiguous bytes per pixel and instruction.
+template <int NCT, int ACT, int SDIL>      // NCT: 16-channel column tiles per K-role wave (cout = 8 waves x 16 NCT)
+__global__ void __launch_bounds__(1024) dwpw_bf16_pp_kernel(DwPwParams p, int n_half) {
+    constexpr int HB = 64, RT = HB / 16, GT = 512;       // pixels per half-tile, row tiles, threads per wave group
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
+    const int ldA = p.C + 8;
+    const __bf16* in = (const __bf16*)p.in;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 3, gw = wave & 7, gt = tid & (GT - 1);
+    __bf16* At = (__bf16*)dsm_raw + (size_t)g * HB * ldA;             // this group's tile [HB][C + 8]
+    float* Wd = (float*)(dsm_raw + (((size_t)2 * HB * ldA * 2 + 15) & ~(size_t)15));   // [10][C], shared
+    for (int i = tid * 4; i < 10 * p.C; i += 1024 * 4) *(f32x4*)(Wd + i) = *(const f32x4*)(p.dw_w + i);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int M32 = p.N * p.Ho * p.Wo;                                // host: < 2^31
+    const int G = gridDim.x;
+    int bid = blockIdx.x;
+    {   // XCD-aware order: the workgroups of one XCD take neighbouring half-tiles (their input windows overlap)
+        const int qq = G >> 3, rem = G & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    }
+    // half-tile of (group g, round k): 2 * (bid + k * G) + g
+    const int rounds = (n_half - 2 * bid + 2 * G - 1) / (2 * G);      // rounds in which group 0 has a half-tile (>= group 1's)
+    const int nslots = 2 * rounds + 1;
+    const int nsteps = p.C / 32, nwt = p.cout / 32;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.pw_w, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 2), 0x00020000);
+    const int pix_b = p.in_ld * 2, row_b = p.Wi * pix_b;
+    const int cg = p.C >> 3;
+    const int c = (gt % cg) * 8;
+    // K role: weights of this wave's NCT column tiles; block w32 = gw * NCT / 2 + (t >> 1) of 32 channels, tile e = t & 1
+    constexpr int PF = 2;
+    bf16x8 bw[PF][NCT];
+    auto load_b = [&](int step, bf16x8* dst) {
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+            const unsigned soff = (unsigned)(step * nwt + gw * (NCT / 2) + (t >> 1)) * 2048u;
+            dst[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + (t & 1) * 1024, soff, 0));
+        }
+    };
+    // run-time ablation switches (LWP_DWPWH_DEBUG, tools only; 0 in production): 1 no depthwise role, 2 no K role, 4 weights of
+    // step 0 only (L1-resident), 8 no stores, 16 depthwise without global loads
+    const int dbg = p.debug;
+    __syncthreads();                                                  // depthwise weights are in LDS
+    for (int s = 0; s < nslots; ++s) {
+        const int d = s - g;                                          // wave-uniform
+        if (d >= 0 && (d & 1) == 0) {
+            // ---------------- depthwise role: half-tile of round d / 2 into this group's tile
+            const int h = 2 * (bid + (d >> 1) * G) + g;
+            if (h < n_half && !(dbg & 1)) {
+                auto ldw = [&](unsigned off) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(irsrc, (dbg & 16) ? 0x80000000u : off, 0, 0)); };
+                struct f32x8 { f32x4 lo, hi; };
+                auto wtap = [&](int t) { return f32x8{*(const f32x4*)(Wd + t * p.C + c), *(const f32x4*)(Wd + t * p.C + c + 4)}; };
+                auto fma8 = [&](f32x8& a, const bf16x8& x, const f32x8& w) {
+                    const f32x4 xl = {(float)x[0], (float)x[1], (float)x[2], (float)x[3]}, xh = {(float)x[4], (float)x[5], (float)x[6], (float)x[7]};
+                    a.lo += xl * w.lo; a.hi += xh * w.hi;
+                };
+                auto finish = [&](const f32x8& a, int row) {
+                    const bf16x8 o = {(__bf16)act_f(a.lo.x, ACT), (__bf16)act_f(a.lo.y, ACT), (__bf16)act_f(a.lo.z, ACT), (__bf16)act_f(a.lo.w, ACT),
+                                      (__bf16)act_f(a.hi.x, ACT), (__bf16)act_f(a.hi.y, ACT), (__bf16)act_f(a.hi.z, ACT), (__bf16)act_f(a.hi.w, ACT)};
+                    *(bf16x8*)(At + row * ldA + c) = o;
+                };
+                constexpr int PXG = 2;
+                const int Wo = p.Wo, Ho = p.Ho;
+                const int gadv = GT / cg;
+                const int adv = gadv * PXG, adv_y = adv / Wo, adv_x = adv - adv_y * Wo;
+                int grp = gt / cg;
+                int m = h * HB + grp * PXG;
+                int xo, yo, img;
+                {
+                    const unsigned q1 = (unsigned)m / (unsigned)Wo;
+                    xo = m - (int)q1 * Wo;
+                    img = (int)(q1 / (unsigned)Ho);
+                    yo = (int)q1 - img * Ho;
+                }
+                for (; grp < HB / PXG; grp += gadv) {
+                    const int row0 = grp * PXG;
+                    if (m + PXG <= M32 && xo + PXG <= Wo) {
+                        constexpr int NV = PXG + 2 * SDIL;
+                        const int base = ((img * p.Hi + yo) * p.Wi + xo) * pix_b + c * 2;
+                        f32x8 a[PXG];
+                        const f32x8 bias = wtap(9);
+#pragma unroll
+                        for (int i = 0; i < PXG; ++i) a[i] = bias;
+                        bf16x8 win[3][NV];
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int yy = yo + (ky - 1) * SDIL;
+                            const bool rok = yy >= 0 && yy < p.Hi;
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) {
+                                const int xx = xo + j - SDIL;
+                                win[ky][j] = ldw((rok && xx >= 0 && xx < p.Wi) ? (unsigned)(base + (ky - 1) * SDIL * row_b + (j - SDIL) * pix_b) : 0x80000000u);
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) {
+                            const f32x8 w = wtap(t);
+#pragma unroll
+                            for (int i = 0; i < PXG; ++i) fma8(a[i], win[t / 3][i + (t % 3) * SDIL], w);
+                        }
+#pragma unroll
+                        for (int i = 0; i < PXG; ++i) finish(a[i], row0 + i);
+                    } else {
+                        int xi = xo, yi = yo, im = img;
+#pragma unroll 1
+                        for (int i = 0; i < PXG; ++i) {               // groups that cross an image row or the end of the tensor
+                            const bool ok = m + i < M32;
+                            const int base = ((im * p.Hi + yi) * p.Wi + xi) * pix_b + c * 2;
+                            bf16x8 x[9];
+#pragma unroll
+                            for (int t = 0; t < 9; ++t) {
+                                const int dy = (t / 3 - 1) * SDIL, dx = (t % 3 - 1) * SDIL;
+                                const bool inb = ok && yi + dy >= 0 && yi + dy < p.Hi && xi + dx >= 0 && xi + dx < p.Wi;
+                                x[t] = ldw(inb ? (unsigned)(base + dy * row_b + dx * pix_b) : 0x80000000u);
+                            }
+                            f32x8 a = wtap(9);
+#pragma unroll
+                            for (int t = 0; t < 9; ++t) fma8(a, x[t], wtap(t));
+                            finish(a, row0 + i);
+                            if (++xi == Wo) { xi = 0; if (++yi == Ho) { yi = 0; ++im; } }
+                        }
+                    }
+                    m += adv;
+                    xo += adv_x; yo += adv_y;
+                    if (xo >= Wo) { xo -= Wo; ++yo; }
+                    while (yo >= Ho) { yo -= Ho; ++img; }
+                }
+            }
+        } else if (d >= 1) {
+            // ---------------- K-loop + store role: the half-tile this group filled in the previous slot
+            const int h = 2 * (bid + ((d - 1) >> 1) * G) + g;
+            if (h < n_half && !(dbg & 2)) {
+                load_b(0, bw[0]);
+                f32x4 acc[RT][NCT];
+#pragma unroll
+                for (int a = 0; a < RT; ++a)
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const __bf16* x_lane = At + i16 * ldA + 8 * q;
+                auto one = [&](int step, auto P_) {
+                    constexpr int P = decltype(P_)::value;
+                    const int nxt = step + PF - 1 < nsteps ? step + PF - 1 : nsteps - 1;
+                    load_b((dbg & 4) ? 0 : nxt, bw[(P + PF - 1) % PF]);   // unconditional (clamped): exact vmcnt counting
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int a = 0; a < RT; ++a) {
+                        const bf16x8 xv = *(const bf16x8*)(x_lane + a * 16 * ldA + step * 32);
+#pragma unroll
+                        for (int t = 0; t < NCT; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[P][t], xv, acc[a][t], 0, 0, 0);
+                    }
+                };
+                int s0 = 0;
+                for (; s0 + PF <= nsteps; s0 += PF) {
+                    one(s0, std::integral_constant<int, 0>{});
+                    one(s0 + 1, std::integral_constant<int, 1>{});
+                }
+                if (s0 < nsteps) one(s0, std::integral_constant<int, 0>{});
+                // store: lane (pixel i16, q) holds channels n0 + 32 u + 8 q + 4 e + r in acc[a][2 u + e][r]
+                __bf16* out = (__bf16*)p.out;
+                const int n0 = gw * 16 * NCT;
+#pragma unroll
+                for (int u = 0; u < NCT / 2; ++u) {
+                    const int n = n0 + 32 * u + 8 * q;
+                    const f32x4 b0 = *(const f32x4*)(p.pw_b + n), b1 = *(const f32x4*)(p.pw_b + n + 4);
+#pragma unroll
+                    for (int a = 0; a < RT; ++a) {
+                        const int m = h * HB + a * 16 + i16;
+                        const f32x4 v0 = acc[a][2 * u] + b0, v1 = acc[a][2 * u + 1] + b1;
+                        const bf16x8 o = {(__bf16)act_f(v0.x, ACT), (__bf16)act_f(v0.y, ACT), (__bf16)act_f(v0.z, ACT), (__bf16)act_f(v0.w, ACT),
+                                          (__bf16)act_f(v1.x, ACT), (__bf16)act_f(v1.y, ACT), (__bf16)act_f(v1.z, ACT), (__bf16)act_f(v1.w, ACT)};
+                        if (m < M32 && !(dbg & 8)) *(bf16x8*)(out + (int64_t)m * p.out_ld + n) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NCT, int ACT, int SDIL>
+static hipError_t launch_dwpw_bf16_pp_t(const DwPwParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
+    const int n_half = (int)((M + 63) / 64);
+    const size_t lds = (((size_t)2 * 64 * (p.C + 8) * 2 + 15) & ~(size_t)15) + (size_t)10 * p.C * sizeof(float);
+    static LdsAttrOnce attr;
+    hipError_t e = attr.ensure((const void*)dwpw_bf16_pp_kernel<NCT, ACT, SDIL>, 160 * 1024);
+    if (e != hipSuccess) return e;
+    int grid = device_cu_count();
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    if (T.dwpw_pp_grid > 0) grid = T.dwpw_pp_grid;
+    if (grid > (n_half + 1) / 2) grid = (n_half + 1) / 2;
+    hipLaunchKernelGGL((dwpw_bf16_pp_kernel<NCT, ACT, SDIL>), dim3(grid), dim3(1024), lds, s, p, n_half);
+    return hipGetLastError();
+}
+
+// two-half-tile form for the wide blocks at large M; *used = false: the caller takes the two-phase kernel
+static hipError_t try_dwpw_bf16_pp(const DwPwParams& p, hipStream_t s, bool* used) {
+    *used = false;
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    // LWP_DWPW_PP "1": on, at every size it supports (tests, tools).  OFF by default — measured at batch 32 (round 3): 512 -> 512
+    // 128.4 us against 119 for the two-phase kernel, 256 -> 512 69.9 against 76.  Run-time ablation of the 512 -> 512 layer (us):
+    // depthwise role alone 56.9 (54.7 without its global loads: VALU / LDS-issue bound on 2 waves per SIMD), K role alone 79.5
+    // (62 without stores: 2.5x its MFMA bound on 2 waves per SIMD; weights kept L1-resident change nothing), both 128.4 —
+    // the two roles do NOT overlap: an MFMA holds its SIMD's issue port 8 of 16 cycles, every VALU instruction 2-4, and with two
+    // waves per role neither hides its own latencies; four waves of one role per SIMD (the two-phase kernel) are as fast.
+    if (T.dwpw_pp != 1) return hipSuccess;
+    const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
+    if (p.stride != 1 || (p.dil != 1 && p.dil != 2) || p.res || p.Hi != p.Ho || p.Wi != p.Wo) return hipSuccess;
+    if ((p.C != 256 && p.C != 512) || (p.cout != 256 && p.cout != 512)) return hipSuccess;
+    if (!(p.act_dw == ACT_RELU && p.act_pw == ACT_RELU)) return hipSuccess;
+    if ((p.out_ld & 7) || (((uintptr_t)p.out) & 15) || (p.in_ld & 7)) return hipSuccess;
+    if (M >= (1ll << 31) - 128 || (int64_t)p.N * p.Hi * p.Wi * p.in_ld * 2 >= (1ll << 31)) return hipSuccess;
+    if ((size_t)2 * 64 * (p.C + 8) * 2 + 16 + (size_t)40 * p.C > 160 * 1024) return hipSuccess;
+    *used = true;
+    LWP_VARIANT(p, "dwpw_bf16_pp<%d,dil=%d>", p.cout / 128, p.dil);
+    DwPwParams q = p;
+    q.debug = T.dwpwh_debug;
+    if (p.cout == 512) return p.dil == 2 ? launch_dwpw_bf16_pp_t<4, ACT_RELU, 2>(q, s) : launch_dwpw_bf16_pp_t<4, ACT_RELU, 1>(q, s);
+    return p.dil == 2 ? launch_dwpw_bf16_pp_t<2, ACT_RELU, 2>(q, s) : launch_dwpw_bf16_pp_t<2, ACT_RELU, 1>(q, s);
+}
+
 // Measured and dropped: persistent workgroups (a tile loop around the body, grid = resident workgroups): 3-10 % faster than the same
 // code launched one workgroup per row block, but the loop keeps more values live across the phases (4-39 spilled VGPRs at the
 // 128-VGPR cap of the 16-wave workgroups) and every layer ended 5-25 % SLOWER than the plain form below.
@@ -286,8 +556,15 @@ static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
 // depthwise from LDS at two waves per SIMD 104 us, and the in-order vmcnt makes the wave wait for its own output stores when
 // it next needs a DMA piece (63 us of "epilogue").  The depthwise conv is VALU-instruction-bound (~19 instructions per output
 // element in f32 on bf16 inputs), not load-bound: the lever that remains is fewer instructions (v_dot2_f32_bf16 on tap pairs).
-hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s) {
+hipError_t launch_dwpw_bf16(const DwPwParams& p_in, hipStream_t s) {
+    DwPwParams p = p_in;
+    p.debug = (p.tune ? *p.tune : default_tuning()).dwpwh_debug;      // run-time A/B bits (tools): 64 = direct-store epilogue
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
+    {
+        bool used = false;
+        hipError_t e = try_dwpw_bf16_pp(p, s, &used);
+        if (e != hipSuccess || used) return e;
+    }
     const int nw = p.cout / 32;
     int bm = 16;
     if (M / 16 >= 2048) bm = 32;

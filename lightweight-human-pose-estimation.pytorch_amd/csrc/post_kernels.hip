@@ -427,8 +427,7 @@ hipError_t launch_publish(int N, PostWorkspace& ws, void* host_block, hipStream_
 // produced separably through LDS from the (PTH/R+6) x (PTW/R+6) low-res patch: horizontal pass, then vertical
 // pass — the same two-pass arithmetic as sample_map / upsample_kernel, so the bits are identical, but with ~10x
 // fewer global loads and no per-pixel index arithmetic.  R = 1: the map is already full resolution.
-constexpr int PTH = 16, PTW = 32;
-template <int R>
+template <int R, int PTH, int PTW>
 __global__ void __launch_bounds__(256) find_peaks_kernel(MapView heat, PostWorkspace ws) {
     constexpr int LH = PTH / R + 6, LW = PTW / R + 6;
     __shared__ float lo[R == 1 ? 1 : LH][R == 1 ? 1 : LW + 1];
@@ -509,14 +508,29 @@ __global__ void __launch_bounds__(256) find_peaks_kernel(MapView heat, PostWorks
         }
     }
 }
-hipError_t launch_find_peaks(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s) {
+template <int PTH, int PTW>
+static hipError_t launch_find_peaks_t(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s) {
     const int Hf = heat.h * ratio, Wf = heat.w * ratio;
     const int tiles = ((Wf + PTW - 1) / PTW) * ((Hf + PTH - 1) / PTH);
     const dim3 grid(tiles, ntypes, N);
-    if (ratio == 1) hipLaunchKernelGGL(find_peaks_kernel<1>, grid, dim3(256), 0, s, heat, ws);
-    else if (ratio == 4) hipLaunchKernelGGL(find_peaks_kernel<4>, grid, dim3(256), 0, s, heat, ws);
-    else hipLaunchKernelGGL(find_peaks_kernel<8>, grid, dim3(256), 0, s, heat, ws);
+    if (ratio == 1) hipLaunchKernelGGL((find_peaks_kernel<1, PTH, PTW>), grid, dim3(256), 0, s, heat, ws);
+    else if (ratio == 4) hipLaunchKernelGGL((find_peaks_kernel<4, PTH, PTW>), grid, dim3(256), 0, s, heat, ws);
+    else hipLaunchKernelGGL((find_peaks_kernel<8, PTH, PTW>), grid, dim3(256), 0, s, heat, ws);
     return hipGetLastError();
+}
+hipError_t launch_find_peaks(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s, const Tuning* tune) {
+    // tile of full-resolution pixels per workgroup: 16 x 32 while the grid is small (one frame: 2376 workgroups at 184 x 328), 32 x 64
+    // when many frames are in the batch (four barrier phases per workgroup: fewer, fatter workgroups).  Measured at batch 32
+    // (round 3): 116 us (16 x 32), 84 (32 x 32), 96 (16 x 64), 81 (32 x 64); at batch 1 10.1 / 10.5 us for 16 x 32 / 32 x 64
+    const Tuning& T = tune ? *tune : default_tuning();
+    const int Hf = heat.h * ratio, Wf = heat.w * ratio;
+    const int64_t wgs = (int64_t)((Wf + 31) / 32) * ((Hf + 15) / 16) * ntypes * N;
+    int sel = wgs >= 16384 ? 3 : 0;
+    if (T.peak_tile >= 0) sel = T.peak_tile;                      // LWP_PEAK_TILE 0..3 (A/B)
+    if (sel == 1) return launch_find_peaks_t<32, 32>(heat, N, ntypes, ratio, ws, s);
+    if (sel == 2) return launch_find_peaks_t<16, 64>(heat, N, ntypes, ratio, ws, s);
+    if (sel == 3) return launch_find_peaks_t<32, 64>(heat, N, ntypes, ratio, ws, s);
+    return launch_find_peaks_t<16, 32>(heat, N, ntypes, ratio, ws, s);
 }
 
 // ------------------------------------------------------------------------------------------------ sort + NMS
@@ -625,6 +639,12 @@ __global__ void __launch_bounds__(256) score_pairs_kernel(MapView paf, int ratio
     const int sub = threadIdx.x & 15;
     const int lane = threadIdx.x & 63;
     const int grp0 = lane & ~15;                                   // first lane of this 16-lane group
+    // the two "first pair whose mid-point test failed / passed" orders are minima over ALL pairs of the frame: every pair used to
+    // issue a 64-bit atomicMin on the frame's flag word — ~3700 same-address atomics per frame, which serialise at the memory side
+    // (the dominant cost of this kernel at batch 32).  They are reduced in LDS first: one global atomic per workgroup and flag.
+    __shared__ unsigned long long s_min[2];
+    if (threadIdx.x < 2) s_min[threadIdx.x] = ~0ull;
+    __syncthreads();
     const int npair_iters = (npairs + SP_BLOCKS * 16 - 1) / (SP_BLOCKS * 16);
     for (int itp = 0; itp < npair_iters; ++itp) {                  // uniform trip count: shuffles need all lanes
         const int p = (itp * SP_BLOCKS + blockIdx.x) * 16 + (threadIdx.x >> 4);
@@ -661,9 +681,9 @@ __global__ void __launch_bounds__(256) score_pairs_kernel(MapView paf, int ratio
         if (live && sub == 0) {
             const unsigned long long order = ((unsigned long long)limb << 32) | (unsigned)p;
             if (!(mid > -100.0)) {
-                atomicMin(&fl[1], order);
+                atomicMin(&s_min[0], order);
             } else {
-                atomicMin(&fl[2], order);
+                atomicMin(&s_min[1], order);
                 double rat = cnt > 0 ? acc / (double)cnt : 0.0;
                 const double pen = __dadd_rn(height_n / norm, -1.0);
                 rat = __dadd_rn(rat, pen < 0.0 ? pen : 0.0);
@@ -678,6 +698,8 @@ __global__ void __launch_bounds__(256) score_pairs_kernel(MapView paf, int ratio
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_min[threadIdx.x] != ~0ull) atomicMin(&fl[1 + threadIdx.x], s_min[threadIdx.x]);
 }
 hipError_t launch_score_pairs(const MapView& paf, int N, int ratio, int demo, PostWorkspace& ws, hipStream_t s) {
     hipLaunchKernelGGL(score_pairs_kernel, dim3(SP_BLOCKS, 19, N), dim3(256), 0, s, paf, ratio, demo, ws);
