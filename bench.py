@@ -628,7 +628,7 @@ def measure_extras(out, args, eng, engines, net, sd, x, x_np, step, run_steps, l
         resize + normalize + pad on the device (lwp_preprocess_u8), then the same pass.  Serial steps, one stream."""
         fr = synth.make_frames(4, args.height, args.width, seed0=100)
         def one(i):
-            xx, _, _ = eng.preprocess_u8(fr[i % 4], args.height, 8)
+            xx, _, _ = eng.preprocess_u8(fr[i % 4], args.height, 8, hand_over=False)    # as demo._prepare: the tensor is internal to infer_fast
             eng.infer_poses_async(xx, 4, True)
             return eng.fetch_poses()
         for i in range(5):
@@ -647,7 +647,7 @@ def measure_extras(out, args, eng, engines, net, sd, x, x_np, step, run_steps, l
                 if len(pending) >= 2 * E:
                     pe, ps = pending.pop(0)
                     r = pe.pipeline_fetch(ps)
-                xx, _, _ = e.preprocess_u8(fr[i % 4], args.height, 8)
+                xx, _, _ = e.preprocess_u8(fr[i % 4], args.height, 8, hand_over=False)
                 e.pipeline_submit(xx, slot, 4, True)
                 pending.append((e, slot))
             for pe, ps in pending:

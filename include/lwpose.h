@@ -71,7 +71,10 @@ const char* lwp_last_error(lwp_handle h);
  *      the work queued on `s` so far (the producers of its inputs and the last users of the buffers it overwrites), and (b) makes
  *      `s` wait for the results it leaves on the device.  `caller_stream` is a hipStream_t (NULL = the legacy default stream,
  *      which is torch's default current stream).  enable = 0 restores the initial state: no ordering, the caller synchronises
- *      (lwp_synchronize) around device-memory hand-overs.  Host-memory results are complete on return in both modes. */
+ *      (lwp_synchronize) around device-memory hand-overs.  enable = 2: (a) only — device results stay on the handle's stream for
+ *      its own next call (the frame tensor between lwp_preprocess_u8 and lwp_infer_poses inside infer_fast, demo.py:59-68, never
+ *      meets the caller's stream), which saves the cross-queue wait.  An idle caller stream costs nothing in any mode (it is
+ *      queried first).  Host-memory results are complete on return in all modes. */
 int lwp_set_stream(lwp_handle h, void* caller_stream, int enable);
 
 /* capacities of the post-processing lists (defaults 2048 / 128 / 4096 / 256); overflow => LWP_ERR_CAPACITY */

@@ -11,7 +11,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "liblwpose_hip.so")
-SOURCES = ["net_graph.cpp", "net_kernels.hip", "net_kernels_bf16.hip", "post_kernels.hip", "capi.cpp"]
+SOURCES = ["net_graph.cpp", "net_kernels.hip", "net_kernels_bf16.hip", "net_kernels_tiled.hip", "post_kernels.hip", "capi.cpp"]
 HEADERS = ["lwp_internal.h", os.path.join("..", "..", "include", "lwpose.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wall", "-Wno-unused-result", "-DNDEBUG"]
 # the post-processing must reproduce NumPy's separately-rounded float32/float64 arithmetic bit for bit:

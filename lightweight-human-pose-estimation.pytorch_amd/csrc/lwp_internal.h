@@ -92,6 +92,8 @@ struct Tuning {
     int gemm_wp = -1;                                              // LWP_GEMM_WP (-1 unset, else first digit)
     bool has_c3 = false, has_pw = false; int c3[3] = {0, 0, 0}, pw[3] = {0, 0, 0};   // LWP_GEMM_C3 / LWP_GEMM_PW = "BM,BN,KS"
     int dwpw_bm = 0, dwpw_nw = 0, dwpw_debug = 0, dwpwh_debug = 0; // LWP_DWPW_BM, LWP_DWPW_NW, LWP_DWPW_DEBUG, LWP_DWPWH_DEBUG
+    int dwpw_tiled_wgs = 0;                                        // LWP_DWPW_TILED_WGS (experiments: persistent workgroups per CU)
+    int dwpw_tiled = -1;                                           // LWP_DWPW_TILED (front blocks, LDS-tiled fused kernel: 0 off, 1 forced)
     int dwpw_pp_grid = 0;                                          // LWP_DWPW_PP_GRID (tests: persistent grid size, to walk several rounds at small M)
     int dwpw_pp = -1;                                              // LWP_DWPW_PP (bf16 two-half-tile fused kernel: 0 off, 1 forced)
     int heads_rm = 0;                                              // LWP_HEADS_RM
@@ -154,6 +156,9 @@ struct DwPwParams {
 };
 bool dwpw_supported(int C, int cout);
 hipError_t launch_dwpw(const DwPwParams& p, hipStream_t s);
+// LDS-tiled form of the front blocks at large batch (net_kernels_tiled.hip); *used = false: not applicable, the caller goes on
+hipError_t try_dwpw_tiled_f32(const DwPwParams& p, hipStream_t s, bool* used);
+hipError_t try_dwpw_tiled_bf16(const DwPwParams& p, hipStream_t s, bool* used);
 // bf16 storage path (net_kernels_bf16.hip): same parameter structs, activation / packed-weight pointers are bf16
 hipError_t launch_stem_bf16(const StemParams& p, hipStream_t s);
 hipError_t launch_dwpw_bf16(const DwPwParams& p, hipStream_t s);

@@ -1353,6 +1353,11 @@ bool dwpw_supported(int C, int cout) {
 
 hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     const DwPwParams& p = p_in;
+    {
+        bool used = false;
+        hipError_t e = try_dwpw_tiled_f32(p, s, &used);
+        if (e != hipSuccess || used) return e;
+    }
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     const int nw = p.cout / 32;
     // rows per workgroup: the largest of 64 / 32 / 16 that still leaves ~2-4 workgroups per CU (measured at batch 1:
@@ -1361,6 +1366,10 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     int bm = 16;
     if (M / 32 >= 450) bm = 32;
     if (M / 64 >= 900) bm = 64;
+    // 512 output channels (16 waves): a 64-row tile is 132 KB of LDS, so ONE workgroup owns the CU and its depthwise phase runs
+    // with the matrix pipes idle; with 32 rows (66 KB) a second workgroup's K loop covers it.  Measured at batch 32 (round 3):
+    // 512 -> 512 630.6 -> 600.7 us, dilation 2 657.6 -> 644.7, 256 -> 512 360.5 -> 351.3
+    if (bm == 64 && nw >= 16) bm = 32;
     int nw_wg = nw;                                  // waves per workgroup (column split = nw / nw_wg)
     const Tuning& T = p.tune ? *p.tune : default_tuning();
     if (T.dwpw_bm) bm = T.dwpw_bm;                   // LWP_DWPW_BM
@@ -1538,6 +1547,7 @@ Tuning tuning_from_env() {
     if (const char* e = getenv("LWP_GEMM_C3")) t.has_c3 = sscanf(e, "%d,%d,%d", &t.c3[0], &t.c3[1], &t.c3[2]) == 3;
     if (const char* e = getenv("LWP_GEMM_PW")) t.has_pw = sscanf(e, "%d,%d,%d", &t.pw[0], &t.pw[1], &t.pw[2]) == 3;
     geti("LWP_DWPW_BM", &t.dwpw_bm); geti("LWP_DWPW_NW", &t.dwpw_nw); geti("LWP_DWPW_DEBUG", &t.dwpw_debug); geti("LWP_DWPWH_DEBUG", &t.dwpwh_debug);
+    digit("LWP_DWPW_TILED", &t.dwpw_tiled); geti("LWP_DWPW_TILED_WGS", &t.dwpw_tiled_wgs);
     digit("LWP_DWPW_PP", &t.dwpw_pp); geti("LWP_DWPW_PP_GRID", &t.dwpw_pp_grid);
     geti("LWP_HEADS_RM", &t.heads_rm);
     digit("LWP_GEMMH_PERSIST", &t.gemmh_persist);

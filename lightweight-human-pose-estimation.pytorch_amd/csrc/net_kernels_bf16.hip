@@ -562,7 +562,9 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p_in, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     {
         bool used = false;
-        hipError_t e = try_dwpw_bf16_pp(p, s, &used);
+        hipError_t e = try_dwpw_tiled_bf16(p, s, &used);
+        if (e != hipSuccess || used) return e;
+        e = try_dwpw_bf16_pp(p, s, &used);
         if (e != hipSuccess || used) return e;
     }
     const int nw = p.cout / 32;

@@ -12,8 +12,9 @@ from .modules.pose import Pose, track_poses
 
 
 def _prepare(net, img, net_input_height_size, stride, pad_value, img_mean, img_scale):
-    """demo.py:55-64 (resize by height, normalize, pad, to tensor) as one GPU kernel: uint8 frame -> cuda tensor."""
-    return net.engine.preprocess_u8(img, net_input_height_size, stride, pad_value, img_mean, img_scale)
+    """demo.py:55-64 (resize by height, normalize, pad, to tensor) as one GPU kernel: uint8 frame -> cuda tensor.  The tensor never
+    leaves infer_fast / run_demo, so it stays on the engine's stream (no hand-over to torch's current stream)."""
+    return net.engine.preprocess_u8(img, net_input_height_size, stride, pad_value, img_mean, img_scale, hand_over=False)
 
 
 def infer_fast(net, img, net_input_height_size, stride, upsample_ratio, cpu,

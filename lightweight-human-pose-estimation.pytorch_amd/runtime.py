@@ -26,13 +26,14 @@ class Engine(object):
         self._keep = None
 
     # ------------------------------------------------------------------ stream ordering
-    def _order(self, device=None):
+    def _order(self, device=None, hand_over=True):
         """Order the library's stream against torch's CURRENT stream on this GPU with events (lwp_set_stream): no host block.
         The reference's net(x) runs on the current stream (demo.py:64-68); this gives device tensors the same semantics —
-        inputs written by queued torch work are waited for, and torch work queued after the call sees the device results."""
+        inputs written by queued torch work are waited for, and torch work queued after the call sees the device results.
+        ``hand_over=False``: results left on the device stay on the library's stream (for its own next call)."""
         torch = _torch()
         st = torch.cuda.current_stream(torch.device("cuda", self.device_id) if device is None else device)
-        check(lib().lwp_set_stream(self.h.ptr, C.c_void_p(st.cuda_stream), 1), self.h.ptr)
+        check(lib().lwp_set_stream(self.h.ptr, C.c_void_p(st.cuda_stream), 1 if hand_over else 2), self.h.ptr)
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict):
@@ -96,6 +97,7 @@ class Engine(object):
         ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
         if on_dev:
             self._order(t.device)                 # events both ways: the outputs are valid for work queued on torch's current stream
+            # (a frame from preprocess_u8(hand_over=False) is in order on the engine's stream; the outputs still need the hand-over)
         mem = MEM_DEVICE if on_dev else MEM_HOST
         check(lib().lwp_forward(self.h.ptr, t.data_ptr(), mem, N, H, W, ptrs, mem), self.h.ptr)
         return [o.numpy() for o in outs] if is_np else outs
@@ -127,9 +129,11 @@ class Engine(object):
         check(lib().lwp_preprocess_dims(height, width, net_input_height_size, stride, *[C.byref(a) for a in v], pad, C.byref(sc)))
         return v[0].value, v[1].value, v[2].value, v[3].value, [int(a) for a in pad], sc.value
 
-    def preprocess_u8(self, img, net_input_height_size, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1 / 256):
+    def preprocess_u8(self, img, net_input_height_size, stride, pad_value=(0, 0, 0), img_mean=(128, 128, 128), img_scale=1 / 256,
+                      hand_over=True):
         """uint8 HxWx3 frame (numpy or cuda tensor) -> (x: 1x3xH'xW' float32 cuda tensor, scale, pad): the cubic resize,
-        normalize and pad_width of demo.py:55-64 in one kernel."""
+        normalize and pad_width of demo.py:55-64 in one kernel.  ``hand_over=False`` (infer_fast's internal use): x is only meant
+        for this engine's next call — it stays on the engine's stream and that call skips the stream ordering (no events)."""
         torch = _torch()
         if getattr(img, "is_cuda", False):
             if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
@@ -146,8 +150,10 @@ class Engine(object):
         x = torch.empty((1, 3, oh, ow), dtype=torch.float32, device=torch.device("cuda", self.device_id))
         pv = (C.c_double * 3)(*[float(v) for v in pad_value])
         mv = (C.c_double * 3)(*[float(v) for v in img_mean])
-        self._order()                             # x is handed to torch's current stream by event; a host frame may be reused on return
+        self._order(hand_over=hand_over)          # x is handed to torch's current stream by event; a host frame may be reused on return
         check(lib().lwp_preprocess_u8(self.h.ptr, ptr, mem, H, W, net_input_height_size, stride, pv, mv, float(img_scale), x.data_ptr()), self.h.ptr)
+        if not hand_over:
+            x._lwp_stream_owner = self            # produced on this engine's stream, not visible to torch's stream
         return x, scale, pad
 
     @staticmethod
@@ -273,7 +279,7 @@ class Engine(object):
         t = t.detach().to(torch.float32).contiguous()
         N, _, H, W = t.shape
         counts, kpts, ent, ne, kcap, ecap = self._result_buffers(N)
-        if t.is_cuda:
+        if t.is_cuda and getattr(x, "_lwp_stream_owner", None) is not self:
             self._order(t.device)
         check(lib().lwp_infer_poses(self.h.ptr, t.data_ptr(), MEM_DEVICE if t.is_cuda else MEM_HOST, N, H, W, upsample_ratio,
                                     1 if demo else 0, counts.ctypes.data_as(C.POINTER(C.c_int)), kpts.ctypes.data, kcap,
@@ -343,7 +349,8 @@ class Engine(object):
             raise ValueError("input tensor must be contiguous")
         if x.device.index != self.device_id:
             raise ValueError("input is on cuda:%d but the engine lives on cuda:%d" % (x.device.index, self.device_id))
-        self._order(x.device)
+        if getattr(x, "_lwp_stream_owner", None) is not self:     # (a tensor this engine produced on its own stream is in order already)
+            self._order(x.device)
         return x
 
     def infer_poses_async(self, x_cuda, upsample_ratio=4, demo=True):

@@ -1200,3 +1200,42 @@ def test_bf16_two_half_tile_fused_kernel_forced_at_small_ragged_sizes(monkeypatc
             assert np.abs(got[nm] - plain[nm]).max() <= 0.02 * sc, (nm, grid)
         for a, b in zip(outs_f, outs_p):
             assert np.abs(a - b).max() <= 0.03 * max(1.0, float(np.abs(b).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_lds_tiled_front_blocks_forced_at_small_ragged_sizes(monkeypatch, dtype):
+    """dwpw_tiled_kernel (model.1 at batch 32: persistent workgroups over 16 x 8 patches, window through LDS with the next patch's
+    window prefetched, rolling depthwise window, MFMA pointwise, direct stores) forced at 2 x 91 x 149 frames (46 x 75 maps: not a
+    multiple of the patch) with one workgroup per CU-slot walking several patches: against the oracle tap and against the row-block
+    kernel (same arithmetic: fp32 within 1e-5, bf16 within rounding-order noise)."""
+    sd = synth.make_state_dict(1, seed=1)
+    x = net_input(2, 92, 150, seed=403)[:, :, :91, :149].copy()
+    taps = {}
+    net_ref.forward(sd, torch.from_numpy(x), 1, taps)
+
+    def run(tiled):
+        monkeypatch.setenv("LWP_DWPW_TILED", tiled)
+        net = PoseEstimationWithMobileNet(num_refinement_stages=1, dtype=dtype)
+        load_state(net, {"state_dict": sd})
+        net.eval().cuda()
+        ls = [i for i in net.engine.layers() if i["name"] == "model.1.pw"]
+        out = {i["name"]: net.engine.debug_layer_output(x, i["index"]) for i in ls}
+        return out, {i["name"]: net.engine.layer_variant(i["index"]) for i in ls}, net(x)
+    monkeypatch.setenv("LWP_DWPW_TILED_WGS", "1")                  # a small persistent grid: several patches per workgroup, ragged tail
+    got, var_f, outs_f = run("1")
+    monkeypatch.delenv("LWP_DWPW_TILED_WGS")
+    plain, var_p, outs_p = run("0")
+    assert len(got) == 1 and all(v.startswith("dwpw_tiled<") for v in var_f.values()), var_f
+    assert not any(v.startswith("dwpw_tiled<") for v in var_p.values()), var_p
+    for nm in got:
+        r = taps[nm[:-3]].numpy()
+        sc = max(1.0, float(np.abs(r).max()))
+        if dtype == "fp32":
+            assert np.abs(got[nm] - r).max() <= NET_TOL * sc, nm
+            assert np.abs(got[nm] - plain[nm]).max() <= 1e-5 * sc, nm
+        else:
+            assert np.abs(got[nm] - r).max() <= BF16_TOL * sc and np.abs(got[nm] - r).mean() <= BF16_MEAN * sc, nm
+            assert np.abs(got[nm] - plain[nm]).max() <= 0.02 * sc, nm
+    for a, b in zip(outs_f, outs_p):
+        assert np.abs(a - b).max() <= (2e-4 if dtype == "fp32" else 0.03) * max(1.0, float(np.abs(b).max()))

@@ -22,6 +22,11 @@ for cfg in "b32_fp32:--batch 32 --steps 4" "b32_bf16:--batch 32 --dtype bf16 --s
   rm -rf $ROOT/$OUT/rp_$tag
 done
 echo "batch-32 kernel stats done"
+# 1c. BASELINE config 4 (batch 32, nref 3, scales 0.5 / 1.0 / 1.5 from resident uint8 frames): kernel stats of three steps
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/rp_cfg4 -- python3 $ROOT/tools/cfg4_step.py 3 > $ROOT/$OUT/cfg4_steps.txt 2>/dev/null
+cp $ROOT/$OUT/rp_cfg4/*/*_kernel_stats.csv $ROOT/$OUT/kernel_stats_cfg4.csv
+rm -rf $ROOT/$OUT/rp_cfg4
+echo "config 4 kernel stats done"
 # 2. HBM-side traffic counters, one pass each (never together with other trace domains)
 for cfg in "b1_fp32:--batch 1 --steps 20" "b32_fp32:--batch 32 --steps 3" "b32_bf16:--batch 32 --dtype bf16 --steps 3"; do
   tag=${cfg%%:*}; fl=${cfg#*:}
@@ -44,8 +49,13 @@ cd $ROOT
 python3 tools/profile_layers.py --batch 1 > $OUT/launch_table_b1_fp32.txt 2>/dev/null
 python3 tools/profile_layers.py --batch 32 > $OUT/launch_table_b32_fp32.txt 2>/dev/null
 python3 tools/profile_layers.py --batch 32 --dtype bf16 > $OUT/launch_table_b32_bf16.txt 2>/dev/null
+for sz in "368 368 s05" "368 656 s10" "552 984 s15"; do set -- $sz; python3 tools/profile_layers.py --batch 32 --nref 3 --height $1 --width $2 --reps 5 > $OUT/launch_table_cfg4_$3.txt 2>/dev/null; done
 python3 tools/dw_roofline.py 32 > $OUT/depthwise_roofline_b32_fp32.txt 2>/dev/null
 python3 tools/bf16_agreement.py 4 > $OUT/bf16_agreement.json 2>/dev/null
 echo "tables done"
 python3 bench.py > $OUT/bench_default.json 2>/dev/null
+# 4. multi-rank rehearsal of the N > 1 bench path on this ONE card (real engines, gloo instead of RCCL, 4 ranks: the box allows
+#    at most 6 processes on its GPU); every rank checks its replica engines and the ranks' weight digests before timing
+LWP_BENCH_DEVICE=0 LWP_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29517 \
+  bench.py --gpus 4 --steps 20 --warmup 3 --no-cpu-baseline --no-extra-configs > $OUT/bench_rehearsal_4ranks_one_card.json 2>/dev/null || echo "rehearsal failed"
 echo done
