@@ -52,14 +52,17 @@ KERNEL_NAMES = {"stem": ("stem_kernel",), "fused_dw_pw": ("dwpw_kernel", "dwpw_b
                 "dense_3x3": ("gemm_ar_kernel", "gemm_wp_kernel", "gemm_kernel", "gemm_bf16_kernel", "gemm_bf16_ar_kernel")}
 
 
-def layer_work(layers, N, H, W, elt_bytes=4, fused_heads=()):
-    """Algorithmic FLOPs (2*MAC) and bytes (in + out + weights at the storage dtype) per kernel family, and per layer.
-    ``fused_heads``: names of the ".heads.0" layers whose pair runs as ONE kernel — the hidden tensor between the two 1x1
-    convs is then never written or read, so it is not counted."""
+def layer_work(layers, N, H, W, elt_bytes=4, covered=None):
+    """Algorithmic FLOPs (2*MAC) and bytes (in + out + weights at the storage dtype) per kernel family, and per launch.
+    ``covered``: {layer name: name of the layer whose LAUNCH also computes it} — a stage's second head conv inside the fused head
+    kernel, a refinement block's `initial` 1x1 inside the preceding 3x3's epilogue (bf16, large M).  The tensor between the two
+    is then never written or read, so it is not counted, and the covered layer's work belongs to the covering launch's family."""
+    covered = covered or {}
+    covers_something = set(covered.values())
+    cls = {l["name"]: layer_class(l) for l in layers}
     h, w = H, W
     acc = {k: [0.0, 0.0] for k in ("stem", "depthwise", "fused_dw_pw", "gemm_1x1", "dense_3x3")}
-    per_layer = []
-    fused1 = set(n[:-1] + "1" for n in fused_heads)
+    per_launch = {}
     for l in layers:
         hi, wi = h, w
         if l["stride"] == 2:
@@ -77,13 +80,18 @@ def layer_work(layers, N, H, W, elt_bytes=4, fused_heads=()):
             byt = (N * hi * wi * l["cin"] + m_out * l["cout"] + 9 * l["cin"]) * elt_bytes
         else:
             flops = 2.0 * m_out * l["macs_per_pixel"]        # merged heads: zero blocks are not counted
-            a_in = 0 if l["name"] in fused1 else m_out * l["cin"]
-            a_out = 0 if l["name"] in fused_heads else m_out * l["cout"]
+            a_in = 0 if l["name"] in covered else m_out * l["cin"]
+            a_out = 0 if l["name"] in covers_something else m_out * l["cout"]
             byt = (a_in + a_out + l["macs_per_pixel"]) * elt_bytes      # weights = MACs per pixel (merged heads: the non-zero blocks)
-        acc[k][0] += flops
-        acc[k][1] += byt
-        per_layer.append((l["name"], k, flops, byt))
-    return acc, per_layer
+            if l["res"] if "res" in l else False:
+                byt += m_out * l["cout"] * elt_bytes
+        owner = covered.get(l["name"], l["name"])
+        acc[cls[owner]][0] += flops
+        acc[cls[owner]][1] += byt
+        e = per_launch.setdefault(owner, [cls[owner], 0.0, 0.0])
+        e[1] += flops
+        e[2] += byt
+    return acc, [(n, v[0], v[1], v[2]) for n, v in per_launch.items()]
 
 
 def rocprof_average_us(family, dtype):
@@ -221,8 +229,13 @@ def class_rooflines(eng, x, batch, height, width, dtype, dev_ms):
     for v in classes.values():
         v["ms_raw"] = v["ms"]
         v["ms"] = max(v["ms"] - ev_overhead_ms * v["launches"], 0.0)
-    fused_heads = [l["name"] for l in layers if l["name"].endswith(".heads.0") and (l["name"][:-1] + "1") not in launched]
-    work, per_layer = layer_work(layers, batch, height, width, 4 if dtype == "fp32" else 2, fused_heads)
+    covered, last = {}, None                       # layers without a launch of their own ride in the previous launch
+    for l in layers:
+        if l["name"] in launched:
+            last = l["name"]
+        elif last is not None:
+            covered[l["name"]] = last
+    work, per_layer = layer_work(layers, batch, height, width, 4 if dtype == "fp32" else 2, covered)
     pk = MFMA_PEAK_TFLOPS[dtype]
     roofs = {}
     for k, (flops, byt) in work.items():

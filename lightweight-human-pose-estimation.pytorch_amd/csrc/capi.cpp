@@ -470,7 +470,8 @@ static inline float* buf_at(lwp_context* h, const BufRef& r) {
     return (float*)((char*)h->bufs[r.buf] + (size_t)r.coff * (h->dtype == LWP_BF16 ? 2 : 4));
 }
 
-static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int N, int H, int W, float* const* d_outs_nchw) {
+static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int N, int H, int W, float* const* d_outs_nchw,
+                         const Layer* fold = nullptr, bool* folded = nullptr) {
     const Graph& g = h->g;
     const bool h16 = h->dtype == LWP_BF16;
     const float* wts = h->d_blob + l.w_off;
@@ -517,6 +518,11 @@ static int enqueue_layer(lwp_context* h, const Layer& l, const float* d_in, int 
         p.N = N; p.H = dh; p.W = dw;
         p.cin_pad = l.cin_pad; p.cout = l.cout; p.cout_pad = l.cout_pad; p.ks = l.ks; p.dil = l.dil; p.act = l.act;
         p.tune = &h->tune; p.variant = vb;
+        if (fold && folded && h16) {                    // the next 1x1 rides in this launch's epilogue if the launcher takes it
+            p.w2 = h->d_blob + fold->w_off; p.bias2 = h->d_blob + fold->b_off;
+            p.out2 = buf_at(h, fold->dst); p.out2_ld = fold->dst.ld; p.act2 = fold->act;
+            p.fused2 = folded;
+        }
         LAUNCH(h, l.ks == 1 ? KC_PW : KC_C3, h16 ? launch_gemm_bf16(p, h->stream) : launch_gemm(p, h->stream));
     }
     if (vb && h->cur_layer >= 0 && h->cur_layer < (int)h->variants.size()) h->variants[h->cur_layer] = vb;
@@ -574,8 +580,31 @@ static int enqueue_forward(lwp_context* h, const float* d_in, int N, int H, int 
             ++i;
             continue;
         }
-        int rc = enqueue_layer(h, ls[i], d_in, N, H, W, d_outs_nchw);
+        // bf16: a dense 3x3 whose output feeds ONLY the next layer, a 1x1 128 -> 128 (refinement block b's last conv and block b+1's
+        // `initial`, with_mobilenet.py:57-60), hands that layer to its own epilogue when the window-resident kernel runs
+        const Layer* fold = nullptr;
+        if (h->dtype == LWP_BF16 && (int)i + 1 < max_layers && i + 1 < ls.size()) {
+            const Layer& a = ls[i];
+            const Layer& b = ls[i + 1];
+            const bool later_reader = [&]() {
+                for (size_t k = i + 2; k < ls.size(); ++k) {
+                    if ((ls[k].src.buf == a.dst.buf && ls[k].src.coff == a.dst.coff) || (ls[k].res.buf == a.dst.buf)) return true;
+                    if (ls[k].dst.buf == a.dst.buf) return false;         // overwritten before anyone else reads it
+                }
+                return false;
+            }();
+            if (a.kind == L_GEMM && a.ks == 3 && b.kind == L_GEMM && b.ks == 1 && b.src.buf == a.dst.buf && b.src.coff == a.dst.coff &&
+                b.src.ld == a.dst.ld && b.res.buf < 0 && b.out_index < 0 && a.out_index < 0 && b.blocks.empty() && a.cout == 128 &&
+                b.cin_pad == 128 && b.cout_pad == 128 && b.cout == 128 && !later_reader)
+                fold = &b;
+        }
+        bool folded = false;
+        int rc = enqueue_layer(h, ls[i], d_in, N, H, W, d_outs_nchw, fold, &folded);
         if (rc) { h->cur_layer = -1; return rc; }
+        if (folded) {
+            if (h->record_variants && i + 1 < h->variants.size()) h->variants[i + 1] = h->variants[i];
+            ++i;
+        }
     }
     h->cur_layer = -1;
     return LWP_OK;

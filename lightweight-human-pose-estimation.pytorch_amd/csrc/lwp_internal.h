@@ -97,6 +97,7 @@ struct Tuning {
     int dwpw_pp_grid = 0;                                          // LWP_DWPW_PP_GRID (tests: persistent grid size, to walk several rounds at small M)
     int dwpw_pp = -1;                                              // LWP_DWPW_PP (bf16 two-half-tile fused kernel: 0 off, 1 forced)
     int heads_rm = 0;                                              // LWP_HEADS_RM
+    int gemmh_fold = -1;                                           // LWP_GEMMH_FOLD (0: never fold the next 1x1 into the 3x3's epilogue)
     int gemmh_persist = -1, gemmh_ar_off = 0, gemmh_ar_force = 0, gemmh_debug = 0;   // LWP_GEMMH_PERSIST, LWP_GEMMH_AR=0, LWP_GEMMH_AR_FORCE
     bool has_gemmh_ar = false, has_gemmh = false; int gemmh_ar[4] = {0, 0, 0, 0}, gemmh[4] = {0, 0, 0, 0};   // LWP_GEMMH_AR / LWP_GEMMH = "a,b,c,d"
     int upsample_tiled = -1;                                       // LWP_UPSAMPLE_TILED
@@ -141,6 +142,11 @@ struct GemmParams {
     int N, H, W, cin_pad, cout, cout_pad, ks, dil, act;
     int debug = 0;                   // reserved for timing experiments
     const Tuning* tune = nullptr; char* variant = nullptr;
+    // optional second conv fused into the epilogue (bf16 window-resident kernel only): out2 = act2(W2 . bf16(out) + b2), a 1x1 conv
+    // 128 -> 128 over the tile the kernel has just produced; `out` itself is then NOT written.  *fused2 reports whether the
+    // launcher took it (else the caller launches the second layer itself).
+    const void* w2 = nullptr; const float* bias2 = nullptr; void* out2 = nullptr; int out2_ld = 0, act2 = 0;
+    bool* fused2 = nullptr;
 };
 struct DwPwParams {
     const float* in; int in_ld;          // depthwise input, NHWC

@@ -1550,7 +1550,7 @@ Tuning tuning_from_env() {
     digit("LWP_DWPW_TILED", &t.dwpw_tiled); geti("LWP_DWPW_TILED_WGS", &t.dwpw_tiled_wgs);
     digit("LWP_DWPW_PP", &t.dwpw_pp); geti("LWP_DWPW_PP_GRID", &t.dwpw_pp_grid);
     geti("LWP_HEADS_RM", &t.heads_rm);
-    digit("LWP_GEMMH_PERSIST", &t.gemmh_persist);
+    digit("LWP_GEMMH_PERSIST", &t.gemmh_persist); digit("LWP_GEMMH_FOLD", &t.gemmh_fold);
     if (const char* e = getenv("LWP_GEMMH_AR")) {
         if (e[0] == '0' && e[1] == 0) t.gemmh_ar_off = 1;
         else t.has_gemmh_ar = sscanf(e, "%d,%d,%d,%d", &t.gemmh_ar[0], &t.gemmh_ar[1], &t.gemmh_ar[2], &t.gemmh_ar[3]) == 4;

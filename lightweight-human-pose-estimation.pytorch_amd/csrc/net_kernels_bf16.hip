@@ -1039,7 +1039,7 @@ hipError_t launch_heads_bf16(const HeadsParams& p, hipStream_t s) {
 // 256-byte pixel rows (residual added from equally coalesced loads, rounded to bf16 once).
 // DBG (compile time, 0 in production; LWP_GEMMH_DEBUG selects an ablation build of the 256-row configuration):
 // 1 no epilogue, 2 no MFMA, 4 no window staging, 8 no weight stream, 16 no K loop
-template <int BM, int WM, int WN, int KSZ, int BD, int WCH, int DBG = 0>     // WCH: 16-byte window chunks per thread and channel block
+template <int BM, int WM, int WN, int KSZ, int BD, int WCH, int DBG = 0, bool F2 = false>     // WCH: 16-byte window chunks per thread and channel block; F2: fused second conv
 __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p) {
     constexpr int NT = WM * WN * 64;
     constexpr int BN = 128, CIN = 128;
@@ -1303,6 +1303,101 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
         const __bf16* res = (const __bf16*)p.res;
         constexpr int OCH = BM * (BN / 8) / NT;             // 16-byte output chunks per thread
         constexpr int OG = OCH >= 4 ? 4 : OCH;              // chunks per pass (bounds the residual registers)
+        if (F2) {
+            // ---- fused second conv (the next refinement block's `initial` 1x1, with_mobilenet.py:57): the block output of this tile
+            // (t = relu(conv) + residual, rounded to bf16 exactly as the stored tensor would be) becomes the MFMA operand of
+            // out2 = act2(W2 . t + b2) and never goes to memory: 31 MB less written, 31 MB less read and one launch less per block.
+            // pass 1: Ot (f32) + residual -> bf16, written IN PLACE over the head of the same Ot row (row stride stays 528 B): the 16
+            // chunks of a row belong to 16 consecutive lanes of one wave, whose LDS reads of an iteration precede its LDS writes.
+            // The second conv's weights W2 [128][128] go into the TAILS of the first 128 rows (bytes 272 .. 527 of a row are free once
+            // the row has been converted): row n of W2 rides with tile row n, 16 bytes per lane of that row's chunk group.
+            __bf16* Tt = (__bf16*)arm_raw;
+            constexpr int TS = OS * 2;                           // row stride of the bf16 images in elements (528 B)
+            constexpr int W2O = BN + 8;                          // element offset of a row's W2 slot (272 B)
+            const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, BN * CIN * 2, 0x00020000);
+#pragma unroll
+            for (int u0 = 0; u0 < OCH; u0 += OG) {
+                bf16x8 rv[OG], w2v[OG];
+#pragma unroll
+                for (int u = 0; u < OG; ++u) {
+                    const int ch = tid + (u0 + u) * NT;
+                    const int row = ch >> 4, col = (ch & 15) * 8;
+                    const int m = m0 + row;
+                    if (res) rv[u] = (m < M) ? *(const bf16x8*)(res + (int64_t)m * p.res_ld + n0_cur + col) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    w2v[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2r, row < BN ? (unsigned)((row * CIN + col) * 2) : 0x80000000u, 0, 0));
+                }
+                f32x4 v0[OG], v1[OG];
+#pragma unroll
+                for (int u = 0; u < OG; ++u) {
+                    const int ch = tid + (u0 + u) * NT;
+                    const int row = ch >> 4, col = (ch & 15) * 8;
+                    v0[u] = *(const f32x4*)(Ot + row * OS + col); v1[u] = *(const f32x4*)(Ot + row * OS + col + 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);               // all reads of this pass are issued before its first write
+#pragma unroll
+                for (int u = 0; u < OG; ++u) {
+                    const int ch = tid + (u0 + u) * NT;
+                    const int row = ch >> 4, col = (ch & 15) * 8;
+                    const float f[8] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w, v1[u].x, v1[u].y, v1[u].z, v1[u].w};
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(res ? f[e] + (float)rv[u][e] : f[e]);
+                    *(bf16x8*)(Tt + row * TS + col) = o;
+                    if (row < BN) *(bf16x8*)(Tt + row * TS + W2O + col) = w2v[u];
+                }
+            }
+            __syncthreads();
+            // second GEMM: wave (wm, wn) as in the main loop, D row = channel, col = pixel
+            f32x16 acc2[RM][RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.f;
+#pragma unroll
+            for (int s8 = 0; s8 < CIN / 16; ++s8) {
+                bf16x8 xt[RM];
+#pragma unroll
+                for (int i = 0; i < RM; ++i) xt[i] = *(const bf16x8*)(Tt + ((wm * RM + i) * 32 + i32) * TS + 16 * s8 + 8 * h);
+                bf16x8 w2f[RN];
+#pragma unroll
+                for (int j = 0; j < RN; ++j) w2f[j] = *(const bf16x8*)(Tt + ((wn * RN + j) * 32 + i32) * TS + W2O + 16 * s8 + 8 * h);
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[j], xt[i], acc2[i][j], 0, 0, 0);
+            }
+            __syncthreads();                                     // every wave has read the bf16 image: the f32 tile may overwrite it
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const int lp = (wm * RM + i) * 32 + i32;
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = (wn * RN + j) * 32 + 8 * g + 4 * h;
+                        f32x4 v = {acc2[i][j][4 * g], acc2[i][j][4 * g + 1], acc2[i][j][4 * g + 2], acc2[i][j][4 * g + 3]};
+                        v += *(const f32x4*)(p.bias2 + nl);
+                        v.x = act_f(v.x, p.act2); v.y = act_f(v.y, p.act2); v.z = act_f(v.z, p.act2); v.w = act_f(v.w, p.act2);
+                        *(f32x4*)(Ot + lp * OS + nl) = v;
+                    }
+            }
+            __syncthreads();
+            __bf16* out2 = (__bf16*)p.out2;
+#pragma unroll
+            for (int u = 0; u < OCH; ++u) {
+                const int ch = tid + u * NT;
+                const int row = ch >> 4, col = (ch & 15) * 8;
+                const int m = m0 + row;
+                if (m >= M) continue;
+                const f32x4 a0 = *(const f32x4*)(Ot + row * OS + col), a1 = *(const f32x4*)(Ot + row * OS + col + 4);
+                const bf16x8 o = {(__bf16)a0.x, (__bf16)a0.y, (__bf16)a0.z, (__bf16)a0.w, (__bf16)a1.x, (__bf16)a1.y, (__bf16)a1.z, (__bf16)a1.w};
+                *(bf16x8*)(out2 + (int64_t)m * p.out2_ld + col) = o;
+            }
+            __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int u0 = 0; u0 < OCH; u0 += OG) {
             bf16x8 rv[OG];
@@ -1340,12 +1435,12 @@ static size_t gemm_bf16_ar_lds(const GemmParams& p, int BM) {
     return loop > epi ? loop : epi;
 }
 
-template <int BM, int WM, int WN, int KSZ, int BD, int WCH, int DBG = 0>
+template <int BM, int WM, int WN, int KSZ, int BD, int WCH, int DBG = 0, bool F2 = false>
 static hipError_t launch_gemm_bf16_ar_w(const GemmParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.H * p.W;
     const int64_t tiles = ((M + BM - 1) / BM) * (p.cout_pad / 128);
     static LdsAttrOnce attr;
-    hipError_t e = attr.ensure((const void*)gemm_bf16_ar_kernel<BM, WM, WN, KSZ, BD, WCH, DBG>, 160 * 1024);
+    hipError_t e = attr.ensure((const void*)gemm_bf16_ar_kernel<BM, WM, WN, KSZ, BD, WCH, DBG, F2>, 160 * 1024);
     if (e != hipSuccess) return e;
     // persistent workgroups: one per CU (or two when two fit), each walking tiles b, b + G, ...
     const Tuning& T = p.tune ? *p.tune : default_tuning();
@@ -1355,18 +1450,18 @@ static hipError_t launch_gemm_bf16_ar_w(const GemmParams& p, hipStream_t s) {
         const int64_t slots = (int64_t)device_cu_count() * (lds <= 80 * 1024 ? 2 : 1);
         if (grid > slots) grid = slots;
     }
-    hipLaunchKernelGGL((gemm_bf16_ar_kernel<BM, WM, WN, KSZ, BD, WCH, DBG>), dim3((unsigned)grid), dim3(WM * WN * 64), lds, s, p);
+    hipLaunchKernelGGL((gemm_bf16_ar_kernel<BM, WM, WN, KSZ, BD, WCH, DBG, F2>), dim3((unsigned)grid), dim3(WM * WN * 64), lds, s, p);
     return hipGetLastError();
 }
-template <int BM, int WM, int WN, int KSZ, int BD, int DBG = 0>
+template <int BM, int WM, int WN, int KSZ, int BD, int DBG = 0, bool F2 = false>
 static hipError_t launch_gemm_bf16_ar_t(const GemmParams& p, hipStream_t s) {
     // window chunks per thread: two register budgets (the window block waits in registers for nine steps)
     constexpr int NT = WM * WN * 64;
     const int halo = p.ks == 3 ? p.dil * (p.W + 1) : 0;
     const int need = ((BM + 2 * halo) * 8 + NT - 1) / NT;
     constexpr int W_SMALL = ((BM + 2 * 96) * 8 + NT - 1) / NT, W_LARGE = ((BM + 2 * 180) * 8 + NT - 1) / NT;
-    if (need <= W_SMALL) return launch_gemm_bf16_ar_w<BM, WM, WN, KSZ, BD, W_SMALL, DBG>(p, s);
-    if (need <= W_LARGE) return launch_gemm_bf16_ar_w<BM, WM, WN, KSZ, BD, W_LARGE, DBG>(p, s);
+    if (need <= W_SMALL) return launch_gemm_bf16_ar_w<BM, WM, WN, KSZ, BD, W_SMALL, DBG, F2>(p, s);
+    if (need <= W_LARGE) return launch_gemm_bf16_ar_w<BM, WM, WN, KSZ, BD, W_LARGE, DBG, F2>(p, s);
     return hipErrorInvalidValue;
 }
 
@@ -1403,6 +1498,13 @@ static hipError_t try_gemm_bf16_ar(const GemmParams& p, hipStream_t s, bool* use
     GAR_DBG(1) GAR_DBG(2) GAR_DBG(4) GAR_DBG(8) GAR_DBG(16) GAR_DBG(17) GAR_DBG(21) GAR_DBG(10) GAR_DBG(14) GAR_DBG(15)
 #undef GAR_DBG
 #endif
+    // the next layer's 1x1 (128 -> 128) folded into this kernel's epilogue: main configuration, one 128-channel tile per pixel tile
+    if (p.w2 && p.fused2 && T.gemmh_fold != 0 && bm == 256 && wm == 4 && wn == 2 && bd == 3 && p.cout_pad == 128 && p.cout == 128 &&
+        !(p.out2_ld & 7) && !(((uintptr_t)p.out2) & 15)) {
+        *p.fused2 = true;
+        LWP_VARIANT(p, "gemm_bf16_ar<256,4,2,3>+1x1");
+        return launch_gemm_bf16_ar_t<256, 4, 2, 3, 3, 0, true>(p, s);
+    }
 #define GAR_CASE(BM_, WM_, WN_, BD_) if (bm == BM_ && wm == WM_ && wn == WN_ && bd == BD_) return launch_gemm_bf16_ar_t<BM_, WM_, WN_, 3, BD_>(p, s);
     GAR_CASE(256, 4, 2, 3) GAR_CASE(128, 2, 2, 3) GAR_CASE(128, 2, 2, 1) GAR_CASE(128, 4, 2, 3) GAR_CASE(256, 4, 2, 1)
 #undef GAR_CASE

@@ -46,6 +46,9 @@ for name, kc, ms in rows:
         if name.endswith(".heads.0") and ms > 0 and li + 1 < len(layers) and not any(r[0] == layers[li + 1]["name"] for r in rows):
             macs += layers[li + 1]["macs_per_pixel"]          # fused head pair: one launch covers both 1x1 convs
             cout, label = layers[li + 1]["cout"], name[:-2] + "{0,1}"
+        elif l["ksize"] == 3 and li + 1 < len(layers) and layers[li + 1]["ksize"] == 1 and not any(r[0] == layers[li + 1]["name"] for r in rows):
+            macs += layers[li + 1]["macs_per_pixel"]          # the next block's `initial` 1x1 rides in this 3x3's epilogue
+            label = name + " +1x1"
         if l["kind"] in (2, 3):
             rate = "%7.1f TF" % (2.0 * m * macs / (ms * 1e-3) / 1e12)
         elif l["kind"] == 1:
