@@ -27,7 +27,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct f32x8 { f32x4 lo, hi; };
 
-template <bool BF16, int C, int COUT, int S, int PH>
+template <int ACT>
+__device__ __forceinline__ float tl_act(float v) {
+    if (ACT == ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == ACT_ELU) return v > 0.f ? v : __expf(v) - 1.f;      // (bf16 path only: the f32 path keeps expm1f, see launcher)
+    return v;
+}
+
+template <bool BF16, int C, int COUT, int S, int PH, int ACT = ACT_RELU>
 __global__ void __launch_bounds__(256, 3) dwpw_tiled_kernel(DwPwParams p, int tiles_y, int tiles_x, int ntiles) {
     constexpr int PW = 8;
     constexpr int VEC = BF16 ? 8 : 4;                  // channels per 16-byte vector
@@ -175,9 +182,9 @@ __global__ void __launch_bounds__(256, 3) dwpw_tiled_kernel(DwPwParams p, int ti
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int pix = (ly0 + i) * PW + lx;
-            const f32x4 lo = {fmaxf(res[i].lo.x, 0.f), fmaxf(res[i].lo.y, 0.f), fmaxf(res[i].lo.z, 0.f), fmaxf(res[i].lo.w, 0.f)};
+            const f32x4 lo = {tl_act<ACT>(res[i].lo.x), tl_act<ACT>(res[i].lo.y), tl_act<ACT>(res[i].lo.z), tl_act<ACT>(res[i].lo.w)};
             if (BF16) {
-                const f32x4 hi = {fmaxf(res[i].hi.x, 0.f), fmaxf(res[i].hi.y, 0.f), fmaxf(res[i].hi.z, 0.f), fmaxf(res[i].hi.w, 0.f)};
+                const f32x4 hi = {tl_act<ACT>(res[i].hi.x), tl_act<ACT>(res[i].hi.y), tl_act<ACT>(res[i].hi.z), tl_act<ACT>(res[i].hi.w)};
                 const bf16x8 o = {(__bf16)lo.x, (__bf16)lo.y, (__bf16)lo.z, (__bf16)lo.w, (__bf16)hi.x, (__bf16)hi.y, (__bf16)hi.z, (__bf16)hi.w};
                 *(bf16x8*)((__bf16*)til + (size_t)pix * LDT + c) = o;
             } else {
@@ -243,16 +250,23 @@ __global__ void __launch_bounds__(256, 3) dwpw_tiled_kernel(DwPwParams p, int ti
                 if (BF16) {
                     const int nn = nb + 8 * q;
                     const f32x4 b0 = *(const f32x4*)(p.pw_b + nn), b1 = *(const f32x4*)(p.pw_b + nn + 4);
-                    const f32x4 v0 = acc[u][a][0] + b0, v1 = acc[u][a][1] + b1;
-                    const bf16x8 o = {(__bf16)fmaxf(v0.x, 0.f), (__bf16)fmaxf(v0.y, 0.f), (__bf16)fmaxf(v0.z, 0.f), (__bf16)fmaxf(v0.w, 0.f),
-                                      (__bf16)fmaxf(v1.x, 0.f), (__bf16)fmaxf(v1.y, 0.f), (__bf16)fmaxf(v1.z, 0.f), (__bf16)fmaxf(v1.w, 0.f)};
+                    f32x4 v0 = acc[u][a][0] + b0, v1 = acc[u][a][1] + b1;
+                    v0 = f32x4{tl_act<ACT>(v0.x), tl_act<ACT>(v0.y), tl_act<ACT>(v0.z), tl_act<ACT>(v0.w)};
+                    v1 = f32x4{tl_act<ACT>(v1.x), tl_act<ACT>(v1.y), tl_act<ACT>(v1.z), tl_act<ACT>(v1.w)};
+                    if (p.res) {                              // residual (cpm: x + trunk(x)) before the single rounding to bf16
+                        const bf16x8 r = *(const bf16x8*)((const __bf16*)p.res + m * p.res_ld + nn);
+                        v0 += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                        v1 += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+                    }
+                    const bf16x8 o = {(__bf16)v0.x, (__bf16)v0.y, (__bf16)v0.z, (__bf16)v0.w, (__bf16)v1.x, (__bf16)v1.y, (__bf16)v1.z, (__bf16)v1.w};
                     *(bf16x8*)((__bf16*)p.out + m * p.out_ld + nn) = o;
                 } else {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int nn = nb + t * 16 + 4 * q;
                         f32x4 v = acc[u][a][t] + *(const f32x4*)(p.pw_b + nn);
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        v = f32x4{tl_act<ACT>(v.x), tl_act<ACT>(v.y), tl_act<ACT>(v.z), tl_act<ACT>(v.w)};
+                        if (p.res) v += *(const f32x4*)(p.res + m * p.res_ld + nn);
                         *(f32x4*)(p.out + m * p.out_ld + nn) = v;
                     }
                 }
@@ -262,7 +276,7 @@ __global__ void __launch_bounds__(256, 3) dwpw_tiled_kernel(DwPwParams p, int ti
     }
 }
 
-template <bool BF16, int C, int COUT, int S, int PH>
+template <bool BF16, int C, int COUT, int S, int PH, int ACT = ACT_RELU>
 static hipError_t launch_tiled_t(const DwPwParams& p, hipStream_t s) {
     constexpr int ESZ = BF16 ? 2 : 4;
     constexpr int WR = (PH - 1) * S + 3, WC = 7 * S + 3;
@@ -272,11 +286,12 @@ static hipError_t launch_tiled_t(const DwPwParams& p, hipStream_t s) {
     const int64_t tiles = (int64_t)p.N * tiles_y * tiles_x;
     if (tiles >= (1ll << 31) - 1) return hipErrorInvalidValue;
     static LdsAttrOnce attr;
-    if (lds > 48 * 1024) { hipError_t e = attr.ensure((const void*)dwpw_tiled_kernel<BF16, C, COUT, S, PH>, 96 * 1024); if (e != hipSuccess) return e; }
+    if (lds > 48 * 1024) { hipError_t e = attr.ensure((const void*)dwpw_tiled_kernel<BF16, C, COUT, S, PH, ACT>, 96 * 1024); if (e != hipSuccess) return e; }
     // persistent grid: as many workgroups as the chip holds at once (LDS- and register-limited), each walking patches b, b + G, ...
     const Tuning& T = p.tune ? *p.tune : default_tuning();
     int per_cu = (int)((160 * 1024) / (lds + 256));
-    if (per_cu > (BF16 ? 4 : 2)) per_cu = BF16 ? 4 : 2;         // measured at batch 32, 32 -> 64: bf16 104 / 109 / 124 us for 4 / 3 / 2 per CU, f32 244 / 221 / 218
+    constexpr int CAP = BF16 ? 4 : (C == 128 ? 3 : 2);         // measured at batch 32, 32 -> 64: bf16 104 / 109 / 124 us for 4 / 3 / 2 per CU, f32 244 / 221 / 218
+    if (per_cu > CAP) per_cu = CAP;
     if (per_cu < 1) per_cu = 1;
     if (T.dwpw_tiled_wgs > 0) per_cu = T.dwpw_tiled_wgs;        // LWP_DWPW_TILED_WGS (experiments): workgroups per CU
     int64_t grid = (int64_t)256 * per_cu;
@@ -285,7 +300,7 @@ static hipError_t launch_tiled_t(const DwPwParams& p, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) grid = (int64_t)cus * per_cu;
     }
     if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL((dwpw_tiled_kernel<BF16, C, COUT, S, PH>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_y, tiles_x, (int)tiles);
+    hipLaunchKernelGGL((dwpw_tiled_kernel<BF16, C, COUT, S, PH, ACT>), dim3((unsigned)grid), dim3(256), lds, s, p, tiles_y, tiles_x, (int)tiles);
     return hipGetLastError();
 }
 
@@ -296,22 +311,30 @@ static hipError_t try_tiled(const DwPwParams& p, hipStream_t s, bool* used) {
     const Tuning& T = p.tune ? *p.tune : default_tuning();
     if (T.dwpw_tiled == 0) return hipSuccess;                  // LWP_DWPW_TILED "0": off (A/B); "1": at every size (tests)
     constexpr int ESZ = BF16 ? 2 : 4;
-    if (p.dil != 1 || p.res || p.act_dw != ACT_RELU || p.act_pw != ACT_RELU) return hipSuccess;
+    const bool relu = p.act_dw == ACT_RELU && p.act_pw == ACT_RELU, elu = p.act_dw == ACT_ELU && p.act_pw == ACT_ELU;
+    if (p.dil != 1 || !(relu || (elu && BF16))) return hipSuccess;       // (ELU blocks: bf16 only — the f32 path's ELU is expm1f)
+    if (p.res && (!elu || (p.res_ld % 8) || (((uintptr_t)p.res) & 15))) return hipSuccess;
     if (p.in_ld != p.C || (p.out_ld % (BF16 ? 8 : 4)) || (((uintptr_t)p.out) & 15) || (((uintptr_t)p.in) & 15)) return hipSuccess;
     if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * ESZ >= (1ll << 31)) return hipSuccess;      // 32-bit buffer offsets
     const int64_t pixels = (int64_t)p.N * p.Ho * p.Wo;
-    if (T.dwpw_tiled != 1 && pixels < (int64_t)256 * 1024) return hipSuccess;               // small maps: the row-block kernels fill the chip better
+    if (T.dwpw_tiled != 1 && pixels < (int64_t)96 * 1024) return hipSuccess;                // small maps: the row-block kernels fill the chip better
     *used = true;
     LWP_VARIANT(p, "dwpw_tiled<%s,%d,%d,s=%d>", BF16 ? "bf16" : "f32", p.C, p.cout, p.stride);
-#define TL_CASE(C_, CO_, S_, PH_) if (p.C == C_ && p.cout == CO_ && p.stride == S_) return launch_tiled_t<BF16, C_, CO_, S_, PH_>(p, s);
+#define TL_CASE(C_, CO_, S_, PH_) if (relu && p.C == C_ && p.cout == CO_ && p.stride == S_) return launch_tiled_t<BF16, C_, CO_, S_, PH_>(p, s);
+    const bool forced = T.dwpw_tiled == 1;
     TL_CASE(32, 64, 1, 16)
-    // The wider front blocks (64 -> 128 stride 2, 128 -> 128, 128 -> 256 stride 2) stay with the row-block kernels: their windows
-    // are 7 - 19 sixteen-byte pieces per thread, and holding the NEXT patch's pieces in registers through the whole body spills at
-    // the 168-VGPR budget of three workgroups per CU (measured with the spills, batch 32: 2 - 5x slower).  Without the prefetch
-    // (one patch per workgroup) the f32 forms ran 198 / 209 us against 218 / 241 for the row-block kernel, the bf16 forms 109 / 93
-    // against 97 / 85; an LDS-DMA prefetch into a second window buffer is the form to build for them.
-    if (T.dwpw_tiled == 1 && false) { TL_CASE(64, 128, 2, 8) TL_CASE(128, 128, 1, 8) TL_CASE(128, 256, 2, 8) }
+    // the wider blocks take 4-row patches: the NEXT patch's window is 4 - 8 sixteen-byte pieces per thread (8-row patches: 7 - 19,
+    // which spill at the 168-VGPR budget of three workgroups per CU: 2 - 5x slower, measured; 128 -> 256 stride 2 spills even so).
+    // Measured at batch 32 against the row-block kernels (us, round 3): 32 -> 64 bf16 130 -> 109, f32 296 -> 222;
+    // 64 -> 128 stride 2 bf16 95 -> 86, f32 222 -> 185;  128 -> 128 f32 239 -> 222 (three workgroups per CU), bf16 83 -> 98 (slower:
+    // 1.9x halo re-reads on 32-pixel patches) and the ELU blocks of the cpm trunk bf16 28 -> 35 (slower) — those two stay with the
+    // row-block kernel unless forced (tests)
+    TL_CASE(64, 128, 2, 4)
+    if (!BF16 || forced) { TL_CASE(128, 128, 1, 4) }
 #undef TL_CASE
+    if constexpr (BF16) {
+        if (forced && elu && p.C == 128 && p.cout == 128 && p.stride == 1) return launch_tiled_t<true, 128, 128, 1, 4, ACT_ELU>(p, s);   // cpm.trunk
+    }
     *used = false;
     return hipSuccess;
 }

@@ -1205,10 +1205,11 @@ def test_bf16_two_half_tile_fused_kernel_forced_at_small_ragged_sizes(monkeypatc
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_lds_tiled_front_blocks_forced_at_small_ragged_sizes(monkeypatch, dtype):
-    """dwpw_tiled_kernel (model.1 at batch 32: persistent workgroups over 16 x 8 patches, window through LDS with the next patch's
-    window prefetched, rolling depthwise window, MFMA pointwise, direct stores) forced at 2 x 91 x 149 frames (46 x 75 maps: not a
-    multiple of the patch) with one workgroup per CU-slot walking several patches: against the oracle tap and against the row-block
-    kernel (same arithmetic: fp32 within 1e-5, bf16 within rounding-order noise)."""
+    """dwpw_tiled_kernel (the front blocks at batch 32 — 32 -> 64, 64 -> 128 stride 2, 128 -> 128 — and at bf16 the three ELU blocks
+    of the cpm trunk with their residual: persistent workgroups over 16 x 8 / 4 x 8 patches, window through LDS with the next
+    patch's window prefetched, rolling depthwise window, MFMA pointwise, direct stores) forced at 2 x 91 x 149 frames (maps 46 x 75,
+    23 x 38, 12 x 19: none a multiple of the patch) with one workgroup per CU-slot walking several patches: against the oracle
+    taps and against the row-block kernels (same arithmetic: fp32 within 1e-5, bf16 within rounding-order noise)."""
     sd = synth.make_state_dict(1, seed=1)
     x = net_input(2, 92, 150, seed=403)[:, :, :91, :149].copy()
     taps = {}
@@ -1219,17 +1220,18 @@ def test_lds_tiled_front_blocks_forced_at_small_ragged_sizes(monkeypatch, dtype)
         net = PoseEstimationWithMobileNet(num_refinement_stages=1, dtype=dtype)
         load_state(net, {"state_dict": sd})
         net.eval().cuda()
-        ls = [i for i in net.engine.layers() if i["name"] == "model.1.pw"]
+        want = ["model.1.pw", "model.2.pw", "model.3.pw"] + (["cpm.trunk.0.pw", "cpm.trunk.1.pw", "cpm.trunk.2.pw"] if dtype == "bf16" else [])
+        ls = [i for i in net.engine.layers() if i["name"] in want]
         out = {i["name"]: net.engine.debug_layer_output(x, i["index"]) for i in ls}
         return out, {i["name"]: net.engine.layer_variant(i["index"]) for i in ls}, net(x)
     monkeypatch.setenv("LWP_DWPW_TILED_WGS", "1")                  # a small persistent grid: several patches per workgroup, ragged tail
     got, var_f, outs_f = run("1")
     monkeypatch.delenv("LWP_DWPW_TILED_WGS")
     plain, var_p, outs_p = run("0")
-    assert len(got) == 1 and all(v.startswith("dwpw_tiled<") for v in var_f.values()), var_f
+    assert len(got) == (6 if dtype == "bf16" else 3) and all(v.startswith("dwpw_tiled<") for v in var_f.values()), var_f
     assert not any(v.startswith("dwpw_tiled<") for v in var_p.values()), var_p
     for nm in got:
-        r = taps[nm[:-3]].numpy()
+        r = taps["cpm.sum" if nm == "cpm.trunk.2.pw" else nm[:-3]].numpy()       # the last trunk block carries the residual x + trunk(x)
         sc = max(1.0, float(np.abs(r).max()))
         if dtype == "fp32":
             assert np.abs(got[nm] - r).max() <= NET_TOL * sc, nm
