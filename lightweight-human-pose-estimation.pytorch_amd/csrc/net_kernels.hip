@@ -1368,7 +1368,9 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     if (M / 64 >= 900) bm = 64;
     // 512 output channels (16 waves): a 64-row tile is 132 KB of LDS, so ONE workgroup owns the CU and its depthwise phase runs
     // with the matrix pipes idle; with 32 rows (66 KB) a second workgroup's K loop covers it.  Measured at batch 32 (round 3):
-    // 512 -> 512 630.6 -> 600.7 us, dilation 2 657.6 -> 644.7, 256 -> 512 360.5 -> 351.3
+    // 512 -> 512 630.6 -> 600.7 us, dilation 2 657.6 -> 644.7, 256 -> 512 360.5 -> 351.3.  (Measured and dropped: 8 waves x 64
+    // channels on 32-row tiles, 128 VGPRs, so that two WHOLE workgroups share the CU — 662.8 us against 601.3: the per-wave
+    // weight stream doubles and a wave's 16 MFMAs per step no longer hide it.)
     if (bm == 64 && nw >= 16) bm = 32;
     int nw_wg = nw;                                  // waves per workgroup (column split = nw / nw_wg)
     const Tuning& T = p.tune ? *p.tune : default_tuning();
