@@ -238,6 +238,9 @@ int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int H, int W, i
  * pair reports the pair's kernel).  Lets a test prove that the kernel it means to cover is the one that ran: the launchers
  * choose by problem size, and the A/B switches (environment, read once per handle in lwp_create) only override that choice. */
 int lwp_debug_layer_variant(lwp_handle h, int layer_index, char* name, int name_cap);
+/* frames one launch sequence of an N x 3 x H x W call takes (N unless a tensor of the pass would reach the kernels' 2 GiB
+ * addressing range: lwp_forward / lwp_infer_poses* / lwp_pipeline_submit then walk the batch in equal chunks of this size) */
+int lwp_debug_frames_per_pass(lwp_handle h, int N, int H, int W);
 
 #ifdef __cplusplus
 }

@@ -440,7 +440,8 @@ static int frames_per_pass(lwp_context* h, int N, int H, int W) {
     level_dims(H, W, 3, &fh, &fw);
     per = std::max(per, (size_t)fh * fw * std::max(h->g.NH, h->g.NP) * sizeof(float));
     const size_t lim = ((size_t)1 << 31) - 4096;
-    const int64_t nmax = std::max<int64_t>(1, (int64_t)(lim / per));
+    int64_t nmax = std::max<int64_t>(1, (int64_t)(lim / per));
+    if (h->tune.max_frames_per_pass > 0) nmax = std::min<int64_t>(nmax, h->tune.max_frames_per_pass);   // tests
     if (N <= nmax) return N;
     const int64_t chunks = (N + nmax - 1) / nmax;
     return (int)((N + chunks - 1) / chunks);
@@ -1351,6 +1352,11 @@ extern "C" int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     out_dims[0] = N; out_dims[1] = l.cout; out_dims[2] = dh; out_dims[3] = dw;
     return LWP_OK;
+}
+
+extern "C" int lwp_debug_frames_per_pass(lwp_handle h, int N, int H, int W) {
+    if (!h || N <= 0 || H <= 0 || W <= 0) return LWP_ERR_ARG;
+    return frames_per_pass(h, N, H, W);
 }
 
 extern "C" int lwp_debug_layer_variant(lwp_handle h, int idx, char* name, int name_cap) {

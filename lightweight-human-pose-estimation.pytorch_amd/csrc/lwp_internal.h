@@ -101,6 +101,7 @@ struct Tuning {
     int gemmh_persist = -1, gemmh_ar_off = 0, gemmh_ar_force = 0, gemmh_debug = 0;   // LWP_GEMMH_PERSIST, LWP_GEMMH_AR=0, LWP_GEMMH_AR_FORCE
     bool has_gemmh_ar = false, has_gemmh = false; int gemmh_ar[4] = {0, 0, 0, 0}, gemmh[4] = {0, 0, 0, 0};   // LWP_GEMMH_AR / LWP_GEMMH = "a,b,c,d"
     int upsample_tiled = -1;                                       // LWP_UPSAMPLE_TILED
+    int max_frames_per_pass = 0;                                   // LWP_MAX_FRAMES_PER_PASS (tests: split batches as if the 2 GiB limit were reached earlier)
     int peak_tile = -1, pair_form = -1;                            // LWP_PEAK_TILE (find_peaks tile 0..3), LWP_PAIR_FORM (score_pairs variant)
     int heads_f32_max_m = 0;                                       // LWP_HEADS_F32_MAXM (tests: force the fused fp32 head pair at larger M)
 };

@@ -1563,6 +1563,7 @@ Tuning tuning_from_env() {
     digit("LWP_UPSAMPLE_TILED", &t.upsample_tiled);
     digit("LWP_PEAK_TILE", &t.peak_tile); digit("LWP_PAIR_FORM", &t.pair_form);
     geti("LWP_HEADS_F32_MAXM", &t.heads_f32_max_m);
+    geti("LWP_MAX_FRAMES_PER_PASS", &t.max_frames_per_pass);
     return t;
 }
 

@@ -330,6 +330,13 @@ class Engine(object):
         n = dims[0] * dims[1] * dims[2] * dims[3]
         return buf[:n].reshape(dims[0], dims[1], dims[2], dims[3]).copy()
 
+    def frames_per_pass(self, N, H, W):
+        """Frames one launch sequence of an (N,3,H,W) call takes (N unless the batch is split inside the call)."""
+        n = lib().lwp_debug_frames_per_pass(self.h.ptr, N, H, W)
+        if n < 0:
+            raise ValueError("bad shape")
+        return n
+
     def layer_variant(self, layer_index):
         """Kernel variant the last debug_layer_output / profile_launches pass picked for a layer ("" before any)."""
         name = C.create_string_buffer(96)

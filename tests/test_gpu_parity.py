@@ -1023,6 +1023,7 @@ def test_batch_beyond_the_2gib_tensor_limit_is_split_inside_the_call():
     from lwpose_amd import workload
     net, sd = workload.build_net(nref=1, seed=1, device=0, dtype="fp32")
     eng_ = net.engine
+    assert eng_.frames_per_pass(140, 368, 656) == 70 and eng_.frames_per_pass(139, 368, 656) == 139
     x = torch.from_numpy(net_input(140, 368, 656, seed=900)).cuda()
     big = [o.cpu() for o in net(x)]
     for lo in (0, 70):
@@ -1306,3 +1307,43 @@ def test_bf16_folded_initial_1x1_matches_the_separate_launches(monkeypatch):
         sc = max(1.0, float(np.abs(r).max()))
         assert np.abs(lt_f[nm] - r).max() <= BF16_TOL * sc, nm
         assert np.abs(lt_f[nm] - lt_p[nm]).max() <= 0.02 * sc, nm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_batch_split_with_a_ragged_last_chunk(monkeypatch, dtype):
+    """The in-call batch split (frames_per_pass) with the limit lowered to 3 frames (LWP_MAX_FRAMES_PER_PASS): 7 frames run as
+    3 + 3 + 1 — equal chunks are only the common case — through lwp_forward, lwp_infer_poses and lwp_pipeline_submit, and must give
+    the bits of an engine that takes the 7 frames in one pass of the same kernels (maps of 2 x 3 frames select the same kernel
+    configurations as 7 at this size)."""
+    from lwpose_amd import workload
+    x = torch.from_numpy(net_input(7, 128, 192, seed=55)).cuda()
+
+    def run(limit):
+        if limit:
+            monkeypatch.setenv("LWP_MAX_FRAMES_PER_PASS", limit)
+        else:
+            monkeypatch.delenv("LWP_MAX_FRAMES_PER_PASS", raising=False)
+        net, _ = workload.build_net(nref=1, seed=1, device=0, dtype=dtype, height=128, width=192)
+        assert net.engine.frames_per_pass(7, 128, 192) == (3 if limit else 7)        # the split really is in effect
+        outs = [o.cpu().numpy() for o in net(x)]
+        res = net.engine.infer_poses(x, 4, demo=True)
+        net.engine.pipeline_submit(x, 0, 4, True)
+        return outs, res, net.engine.pipeline_fetch(0), net
+    outs_s, res_s, resp_s, net_s = run("3")
+    outs_1, res_1, resp_1, _ = run("")
+    parts = [o.cpu().numpy() for lo, hi in ((0, 3), (3, 6), (6, 7)) for o in net_s(x[lo:hi].contiguous())]
+    tol = 2e-4 if dtype == "fp32" else 0.03
+    for i, (a, b) in enumerate(zip(outs_s, outs_1)):
+        assert np.abs(a - b).max() <= tol * max(1.0, float(np.abs(b).max()))          # (other kernel configurations at N = 7)
+        cat = np.concatenate([parts[i], parts[4 + i], parts[8 + i]])
+        assert np.array_equal(a, cat)                                                # exactly the three separate calls
+    assert sum(len(r[1]) for r in res_s) > 10
+    for fa, fb in zip(res_s, resp_s):
+        for u, v in zip(fa, fb):
+            assert np.array_equal(u, v)
+    for lo, hi in ((0, 3), (3, 6), (6, 7)):
+        part = net_s.engine.infer_poses(x[lo:hi].contiguous(), 4, demo=True)
+        for f in range(hi - lo):
+            for u, v in zip(res_s[lo + f], part[f]):
+                assert np.array_equal(u, v)
