@@ -104,7 +104,7 @@ int lwp_weights_blob_import(lwp_handle h, const void* src_device, size_t bytes);
  *      Runs on the handle's stream and synchronises it before returning when out_mem is host; device outputs are handed
  *      to the caller's stream by an event when lwp_set_stream is in effect (else call lwp_synchronize before reading them).
  *      Any N: the kernels address a tensor with 32-bit byte offsets, so a batch whose tensors would reach 2 GiB (at 368 x 656:
- *      N > 139 in fp32, N > 278 in bf16) is processed in equal chunks inside the call — same results as separate calls.
+ *      N > 138 in fp32, N > 277 in bf16) is processed in equal chunks inside the call — same results as separate calls.
  *      fp32 results depend on the batch size at the 1e-6 level only: kernels (tile shapes, split-K, the fused head pair up to
  *      4096 pixels) are chosen by problem size, and their summation orders differ. */
 int lwp_forward(lwp_handle h, const float* in, int in_mem, int N, int H, int W,

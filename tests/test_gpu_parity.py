@@ -1023,7 +1023,7 @@ def test_batch_beyond_the_2gib_tensor_limit_is_split_inside_the_call():
     from lwpose_amd import workload
     net, sd = workload.build_net(nref=1, seed=1, device=0, dtype="fp32")
     eng_ = net.engine
-    assert eng_.frames_per_pass(140, 368, 656) == 70 and eng_.frames_per_pass(139, 368, 656) == 139
+    assert eng_.frames_per_pass(140, 368, 656) == 70 and eng_.frames_per_pass(138, 368, 656) == 138 and eng_.frames_per_pass(139, 368, 656) == 70
     x = torch.from_numpy(net_input(140, 368, 656, seed=900)).cuda()
     big = [o.cpu() for o in net(x)]
     for lo in (0, 70):
