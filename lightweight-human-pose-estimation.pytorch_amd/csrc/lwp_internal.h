@@ -92,6 +92,7 @@ struct Tuning {
     int gemm_wp = -1;                                              // LWP_GEMM_WP (-1 unset, else first digit)
     bool has_c3 = false, has_pw = false; int c3[3] = {0, 0, 0}, pw[3] = {0, 0, 0};   // LWP_GEMM_C3 / LWP_GEMM_PW = "BM,BN,KS"
     int dwpw_bm = 0, dwpw_nw = 0, dwpw_debug = 0, dwpwh_debug = 0; // LWP_DWPW_BM, LWP_DWPW_NW, LWP_DWPW_DEBUG, LWP_DWPWH_DEBUG
+    int dwpw_pipe = -1;                                            // LWP_DWPW_PIPE (f32 software-pipelined 512-output fused kernel: 0 off, 1 forced)
     int dwpw_tiled_wgs = 0;                                        // LWP_DWPW_TILED_WGS (experiments: persistent workgroups per CU)
     int dwpw_tiled = -1;                                           // LWP_DWPW_TILED (front blocks, LDS-tiled fused kernel: 0 off, 1 forced)
     int dwpw_pp_grid = 0;                                          // LWP_DWPW_PP_GRID (tests: persistent grid size, to walk several rounds at small M)

@@ -1347,6 +1347,177 @@ static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------- fused depthwise -> pointwise, software-pipelined
+// The 512-output f32 blocks at large M (batch 32: 30 % of the step).  In dwpw_kernel all 16 waves of the workgroup that owns the CU
+// run the depthwise phase together (matrix pipes idle), then the K loop together: 600 us per 512 -> 512 layer against an MFMA
+// bound of 410.  A v_mfma_f32_16x16x4_f32 holds its SIMD's issue port a quarter of its 32 cycles, so the vector ALU has room for
+// the WHOLE depthwise phase (~10 % of the K loop's issue time) — if its instructions sit between MFMAs.  Here a PERSISTENT
+// workgroup keeps TWO 32-row tiles in LDS: while the K loop multiplies tile t out of one, every K step also carries one piece of
+// the depthwise computation of tile t + G into the other (step 4i: the nine window loads of the thread's i-th pixel, 4i+1 / 4i+2:
+// the taps, 4i+3: activation + LDS store), so four K steps later the pixel is done and, with four waves per SIMD at different
+// points of their steps, one wave's VALU work runs under the others' MFMAs.  One barrier per tile; the weight ring wraps from the
+// last step to step 0 (the same for every tile), so the stream never drains; stores go straight from the accumulators.
+// Depthwise arithmetic in dwpw_kernel's order (bias, taps row-major), pointwise sums in the same k order: bit-identical results.
+template <int C>     // depthwise channels (256 | 512); 512 output channels = 16 waves x 32
+__global__ void __launch_bounds__(1024) dwpw_pipe_kernel(DwPwParams p, int ntiles) {
+    constexpr int BM = 32, NT = 1024, RT = BM / 16, NSTEP = C / 32;
+    constexpr int ldA = C + 4;
+    constexpr int CG = C / 4;                        // 4-channel chunks per pixel
+    constexpr int PAR = NT / CG;                     // pixels in flight across the workgroup (8 | 16)
+    constexpr int NIT = BM / PAR;                    // pixels per thread and tile (4 | 2)
+    static_assert(NIT * 4 == NSTEP, "one pixel per four K steps");
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    float* Wd = dsm + 2 * BM * ldA;                  // [10][C] depthwise weights + bias
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const int M32 = p.N * p.Ho * p.Wo;               // host: < 2^31
+    const int G = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int qq = G >> 3, rem = G & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    }
+    for (int i = tid * 4; i < 10 * C; i += NT * 4) *(f32x4*)(Wd + i) = *(const f32x4*)(p.dw_w + i);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.pw_w, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4), 0x00020000);
+    const int pix_b = p.in_ld * 4, row_b = p.Wi * pix_b;
+    const int c = (tid % CG) * 4, prow = tid / CG;
+    constexpr int NU = 16;                           // 32-channel output units = waves
+    f32x4 bw[2][4];
+    auto load_b = [&](int step, f32x4* dst) {
+        const unsigned soff = (unsigned)(step * NU + wave_u) * 4096u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, lane * 16 + j * 1024, soff, 0));
+    };
+    // ---- one piece of the depthwise computation of pixel `it` of tile `tl` into the tile buffer Adst
+    f32x4 win[9], pacc;
+    auto p_piece = [&](int tl, int it, int j, float* Adst) {
+        if (j == 0) {
+            const int m = tl * BM + it * PAR + prow;
+            const bool ok = m < M32;
+            const unsigned q1 = (unsigned)m / (unsigned)p.Wo;
+            const int xo = m - (int)q1 * p.Wo;
+            const int img = (int)(q1 / (unsigned)p.Ho);
+            const int yo = (int)q1 - img * p.Ho;
+            const int yc = yo * p.stride, xc = xo * p.stride;
+            const int base = ((img * p.Hi + yc) * p.Wi + xc) * pix_b + c * 4;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = (t / 3 - 1) * p.dil, dx = (t % 3 - 1) * p.dil;
+                const bool in = ok && yc + dy >= 0 && yc + dy < p.Hi && xc + dx >= 0 && xc + dx < p.Wi;
+                win[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irsrc, in ? (unsigned)(base + dy * row_b + dx * pix_b) : 0x80000000u, 0, 0));
+            }
+        } else if (j == 1) {
+            pacc = *(const f32x4*)(Wd + 9 * C + c);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pacc += win[t] * *(const f32x4*)(Wd + t * C + c);
+        } else if (j == 2) {
+#pragma unroll
+            for (int t = 4; t < 9; ++t) pacc += win[t] * *(const f32x4*)(Wd + t * C + c);
+        } else {
+            f32x4 v = pacc;
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            *(f32x4*)(Adst + (it * PAR + prow) * ldA + c) = v;
+        }
+    };
+    __syncthreads();                                 // depthwise weights are in LDS
+    int tile = bid;
+    // prologue: the first tile's depthwise block, not overlapped
+    if (tile < ntiles) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p_piece(tile, it, j, dsm);
+    }
+    load_b(0, bw[0]);
+    __syncthreads();
+    int cur = 0;
+    for (; tile < ntiles; tile += G) {
+        const float* Ac = dsm + cur * BM * ldA;
+        float* An = dsm + (cur ^ 1) * BM * ldA;
+        const int tnext = tile + G < ntiles ? tile + G : tile;       // past the end: this tile again (harmless, keeps every load unconditional)
+        f32x4 acc[RT][2];
+#pragma unroll
+        for (int a = 0; a < RT; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const float* a_lane = Ac + r16 * ldA + 4 * q;
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+            load_b((step + 1) % NSTEP, bw[(step + 1) & 1]);          // the ring wraps: step 0 of the next tile is the same weights
+            __builtin_amdgcn_sched_barrier(0);
+            p_piece(tnext, step >> 2, step & 3, An);
+            const f32x4* bcur = bw[step & 1];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 av[RT];
+#pragma unroll
+                for (int a = 0; a < RT; ++a) av[a] = *(const f32x4*)(a_lane + a * 16 * ldA + step * 32 + 16 * u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int v = u * 8 + j * 2 + t;
+                        const float b = bcur[v >> 2][v & 3];
+#pragma unroll
+                        for (int a = 0; a < RT; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, av[a][j], acc[a][t], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();                             // tile t is multiplied, tile t + G is convolved: the buffers swap roles
+        cur ^= 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int n = wave_u * 32 + t * 16 + 4 * q;
+            const f32x4 bias = *(const f32x4*)(p.pw_b + n);
+#pragma unroll
+            for (int a = 0; a < RT; ++a) {
+                const int m = tile * BM + a * 16 + r16;
+                if (m < M32) {
+                    f32x4 v = acc[a][t] + bias;
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    *(f32x4*)(p.out + (int64_t)m * p.out_ld + n) = v;
+                }
+            }
+        }
+    }
+}
+
+template <int C>
+static hipError_t launch_dwpw_pipe_t(const DwPwParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
+    const int ntiles = (int)((M + 31) / 32);
+    const size_t lds = (size_t)(2 * 32 * (C + 4) + 10 * C) * sizeof(float);
+    static LdsAttrOnce attr;
+    hipError_t e = attr.ensure((const void*)dwpw_pipe_kernel<C>, 160 * 1024);
+    if (e != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    int grid = cus * (lds <= 80 * 1024 ? 2 : 1);
+    if (T.dwpw_pp_grid > 0) grid = T.dwpw_pp_grid;   // LWP_DWPW_PP_GRID (tests: several tiles per workgroup at small M)
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((dwpw_pipe_kernel<C>), dim3(grid), dim3(1024), lds, s, p, ntiles);
+    return hipGetLastError();
+}
+
+static hipError_t try_dwpw_pipe(const DwPwParams& p, hipStream_t s, bool* used) {
+    *used = false;
+    const Tuning& T = p.tune ? *p.tune : default_tuning();
+    if (T.dwpw_pipe == 0) return hipSuccess;                       // LWP_DWPW_PIPE "0": off (A/B); "1": at every size (tests)
+    const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
+    if (p.cout != 512 || (p.C != 256 && p.C != 512) || p.res || p.act_dw != ACT_RELU || p.act_pw != ACT_RELU) return hipSuccess;
+    if ((p.stride != 1 && p.stride != 2) || (p.in_ld & 3) || (p.out_ld & 3) || (((uintptr_t)p.out) & 15) || (((uintptr_t)p.in) & 15)) return hipSuccess;
+    if (M >= (1ll << 31) - 64 || (int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4 >= (1ll << 31)) return hipSuccess;
+    if (T.dwpw_pipe != 1 && M < 32 * 2048) return hipSuccess;      // small problems: one tile per workgroup fills the chip better
+    // measured at batch 32 (us, round 3): 512 -> 512 597.5 -> 576.8, dilation 2 648.6 -> 588.4, 256 -> 512 368.2 -> 373.7 (its K loop is
+    // half as long: the pieces no longer hide) — the 256-channel block keeps the two-phase kernel unless forced.  At the clock the
+    // chip holds under this load (~2.0 GHz) the MFMA bound of a 512 -> 512 layer is ~480 us, not the 410 of the 2.4 GHz peak.
+    if (T.dwpw_pipe != 1 && p.C != 512) return hipSuccess;
+    *used = true;
+    LWP_VARIANT(p, "dwpw_pipe<%d>", p.C);
+    return p.C == 512 ? launch_dwpw_pipe_t<512>(p, s) : launch_dwpw_pipe_t<256>(p, s);
+}
+
 bool dwpw_supported(int C, int cout) {
     return C % 32 == 0 && (cout == 64 || cout == 128 || cout == 256 || cout == 512);
 }
@@ -1356,6 +1527,8 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     {
         bool used = false;
         hipError_t e = try_dwpw_tiled_f32(p, s, &used);
+        if (e != hipSuccess || used) return e;
+        e = try_dwpw_pipe(p, s, &used);
         if (e != hipSuccess || used) return e;
     }
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
@@ -1549,6 +1722,7 @@ Tuning tuning_from_env() {
     if (const char* e = getenv("LWP_GEMM_C3")) t.has_c3 = sscanf(e, "%d,%d,%d", &t.c3[0], &t.c3[1], &t.c3[2]) == 3;
     if (const char* e = getenv("LWP_GEMM_PW")) t.has_pw = sscanf(e, "%d,%d,%d", &t.pw[0], &t.pw[1], &t.pw[2]) == 3;
     geti("LWP_DWPW_BM", &t.dwpw_bm); geti("LWP_DWPW_NW", &t.dwpw_nw); geti("LWP_DWPW_DEBUG", &t.dwpw_debug); geti("LWP_DWPWH_DEBUG", &t.dwpwh_debug);
+    digit("LWP_DWPW_PIPE", &t.dwpw_pipe);
     digit("LWP_DWPW_TILED", &t.dwpw_tiled); geti("LWP_DWPW_TILED_WGS", &t.dwpw_tiled_wgs);
     digit("LWP_DWPW_PP", &t.dwpw_pp); geti("LWP_DWPW_PP_GRID", &t.dwpw_pp_grid);
     geti("LWP_HEADS_RM", &t.heads_rm);

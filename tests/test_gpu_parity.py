@@ -1347,3 +1347,37 @@ def test_batch_split_with_a_ragged_last_chunk(monkeypatch, dtype):
         for f in range(hi - lo):
             for u, v in zip(res_s[lo + f], part[f]):
                 assert np.array_equal(u, v)
+
+
+@pytest.mark.gpu
+def test_fp32_software_pipelined_fused_kernel_forced_at_small_ragged_sizes(monkeypatch):
+    """dwpw_pipe_kernel (the 512-output f32 blocks at batch 32: persistent workgroups, two 32-row tiles in LDS, the depthwise block
+    of the next tile computed piecewise inside the K loop of the current one) forced at M = 2 x 12 x 19 = 456 pixels (15 tiles, the
+    last one ragged) with persistent grids of 2, 3 and 15 workgroups (8 / 5 / 1 tiles each, odd tails): model.6 .. model.11
+    (256 -> 512, 512 -> 512 with dilation 2 and 1) must be BIT-IDENTICAL to the two-phase kernel (same arithmetic, same order) and
+    within the network tolerance of the oracle."""
+    sd = synth.make_state_dict(1, seed=1)
+    x = net_input(2, 92, 150, seed=405)[:, :, :91, :149].copy()
+    taps = {}
+    net_ref.forward(sd, torch.from_numpy(x), 1, taps)
+
+    def run(pipe, grid):
+        monkeypatch.setenv("LWP_DWPW_PIPE", pipe)
+        monkeypatch.setenv("LWP_DWPW_PP_GRID", grid)
+        net = PoseEstimationWithMobileNet(num_refinement_stages=1)
+        load_state(net, {"state_dict": sd})
+        net.eval().cuda()
+        ls = [i for i in net.engine.layers() if i["name"] in ("model.%d.pw" % k for k in range(6, 12))]
+        out = {i["name"]: net.engine.debug_layer_output(x, i["index"]) for i in ls}
+        return out, {i["name"]: net.engine.layer_variant(i["index"]) for i in ls}, net(x)
+    plain, var_p, outs_p = run("0", "0")
+    assert not any(v.startswith("dwpw_pipe<") for v in var_p.values()), var_p
+    for grid in ("2", "3", "0"):
+        got, var_f, outs_f = run("1", grid)
+        assert len(got) == 6 and all(v.startswith("dwpw_pipe<") for v in var_f.values()), var_f
+        for nm in got:
+            r = taps[nm[:-3]].numpy()
+            assert np.abs(got[nm] - r).max() <= NET_TOL * max(1.0, float(np.abs(r).max())), (nm, grid)
+            assert np.array_equal(got[nm], plain[nm]), (nm, grid)
+        for a, b in zip(outs_f, outs_p):
+            assert np.array_equal(a, b)
