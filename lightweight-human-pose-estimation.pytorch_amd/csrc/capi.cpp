@@ -1096,8 +1096,11 @@ static int enqueue_poses_chunk(lwp_context* h, const float* d_in, int N, int H, 
     level_dims(H, W, 3, &fh, &fw);
     const int cc = g.cat_channels;
     MapView heat, paf;
-    if (h->dtype == LWP_BF16) {
-        // the concat buffer is bf16: the last stage's heads ALSO write f32 NCHW maps for the post-processing
+    // bf16: the concat buffer is bf16, so the last stage's heads ALSO write f32 NCHW maps for the post-processing.  f32: the maps
+    // could be read in place from the (NHWC) concat buffer, but the 4 x 4 footprint of a cubic sample is 4 cache lines in a
+    // channel plane and 16 in channels-last rows: pair scoring at batch 32 runs 255 us on the concat buffer and ~80 on planes
+    // (LWP_POST_NCHW=0: the in-place form, A/B)
+    if (h->dtype == LWP_BF16 || (with_post && h->tune.post_nchw != 0)) {
         const int nout = 2 * (1 + g.nref);
         std::vector<float*> outs(nout, nullptr);
         const size_t hb = (size_t)N * g.NH * fh * fw * sizeof(float), pb = (size_t)N * g.NP * fh * fw * sizeof(float);
