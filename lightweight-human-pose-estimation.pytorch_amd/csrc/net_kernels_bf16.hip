@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
     const int R = BM + 2 * halo;                       // window rows
     __bf16* Aw = (__bf16*)arm_raw;                     // [R + 1][CS]  (last row: zeros)
     __bf16* zrow = Aw + (size_t)R * CS;
-    __bf16* Bs = zrow + CS;                            // [2][BN][HLD]
+    __bf16* Bs = zrow + CS;                            // [3][BN][HLD]: step k reads buffer k % 3 while step k + 2's tile is written
     const __bf16* in = (const __bf16*)p.in;
     const __bf16* wgt = (const __bf16*)p.w;
 
@@ -1138,7 +1138,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
     using std::integral_constant;
     typedef integral_constant<bool, false> no_t;
     typedef integral_constant<bool, true> yes_t;
-    static_assert(taps % BD == 0, "the restage step must sit at a fixed ring position");
+    static_assert(BD == 3 && taps % BD == 0, "ring of three: the buffer of a step is its position in the unrolled group");
 
     int tile = bid;
     if (tile < ntiles) prefetch_tile(tile);
@@ -1151,7 +1151,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
             win_load(m0, 1);                               // in flight during the first nine steps
         }
         for (int c = tid * 8; c < CS; c += NT * 8) *(bf16x8*)(zrow + c) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        store_b(0, b_reg[0]);
+        if (!(DBG & 8)) {
+            store_b(0, b_reg[0]);
+            store_b(1, b_reg[1]);
+            load_b(3, b_reg[0]);                           // ring: set s % 3 holds step s; steps 2, 3 (and from step 0 on: 4) are in flight
+        }
 
         // the lane's pixels: window row of the tap (0, 0) and the taps that fall inside the image
         int a_row[RM];
@@ -1195,6 +1199,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < RM; ++i) xa[0][i] = *(const bf16x8*)(Aw + ao[i]);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) wb[0][j] = *(const bf16x8*)(Bs + b_lane + j * 32 * HLD);
 
         // one K step; JB (compile time) = position in the register ring, RESTAGE = the last step on channel block 0.
         // No data-dependent branch inside: look-ahead indices are clamped (the last steps reload / restore harmlessly), so the
@@ -1202,11 +1208,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
         auto do_step = [&](int step, auto JB_, auto RESTAGE_) {
             constexpr int jb = decltype(JB_)::value;
             constexpr bool restage = decltype(RESTAGE_)::value;
-            const int buf = step & 1;
-            if (!(DBG & 8)) load_b(step + BD < nsteps ? step + BD : nsteps - 1, b_reg[jb]);      // set jb held step `step`, which is in LDS already
-            const __bf16* b = Bs + buf * BN * HLD + b_lane;
-#pragma unroll
-            for (int j = 0; j < RN; ++j) wb[0][j] = *(const bf16x8*)(b + j * 32 * HLD);
+            // weight tiles: three LDS buffers, buffer = step % 3 = jb.  Step k multiplies from buffer k % 3, writes step k + 2's tile
+            // (ring set (jb + 2) % 3, requested two steps ago) and requests step k + 4 into the set that held step k + 1 (in LDS since
+            // step k - 1).  Step k + 1's tile is therefore complete BEFORE this step's barrier, so its first fragments — like the
+            // activation ones — are read ahead of the barrier and the MFMAs restart right behind it (with two buffers every step
+            // began with an exposed LDS round trip: ~20 % of the loop).
+            if (!(DBG & 8)) load_b(step + 4 < nsteps ? step + 4 : nsteps - 1, b_reg[(jb + 1) % 3]);
+            const __bf16* b = Bs + jb * BN * HLD + b_lane;
+            const __bf16* bnext = Bs + ((jb + 1) % 3) * BN * HLD + b_lane;
             int an[RM];                                          // next step's activation offsets
 #pragma unroll
             for (int i = 0; i < RM; ++i) an[i] = a_off(step + 1 < nsteps ? step + 1 : step, i);
@@ -1218,9 +1227,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
                     for (int i = 0; i < RM; ++i) xa[n][i] = *(const bf16x8*)(Aw + ao[i] + 16 * (s + 1));
 #pragma unroll
                     for (int j = 0; j < RN; ++j) wb[n][j] = *(const bf16x8*)(b + j * 32 * HLD + 16 * (s + 1));
-                } else if (!restage) {
+                } else {
 #pragma unroll
-                    for (int i = 0; i < RM; ++i) xa[n][i] = *(const bf16x8*)(Aw + an[i]);      // next step, sub-step 0: before the barrier
+                    for (int j = 0; j < RN; ++j) wb[n][j] = *(const bf16x8*)(bnext + j * 32 * HLD);   // next step, sub-step 0: before the barrier
+                    if (!restage) {
+#pragma unroll
+                        for (int i = 0; i < RM; ++i) xa[n][i] = *(const bf16x8*)(Aw + an[i]);
+                    }
                 }
                 if (DBG & 2) {
 #pragma unroll
@@ -1236,7 +1249,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
             }
 #pragma unroll
             for (int i = 0; i < RM; ++i) ao[i] = an[i];
-            if (!(DBG & 8)) store_b(buf ^ 1, b_reg[(jb + 1) % BD]);
+            if (!(DBG & 8)) store_b((jb + 2) % 3, b_reg[(jb + 2) % 3]);
             __syncthreads();
             if (restage) {                                       // every wave is past its last read of block 0: block 1 takes its place
                 if (!(DBG & 4)) win_write();
@@ -1430,7 +1443,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_bf16_ar_kernel(GemmParams p
 
 static size_t gemm_bf16_ar_lds(const GemmParams& p, int BM) {
     const int halo = p.ks == 3 ? p.dil * (p.W + 1) : 0;
-    const size_t loop = ((size_t)(BM + 2 * halo + 1) * (HBK + 8) + (size_t)2 * 128 * HLD) * 2;
+    const size_t loop = ((size_t)(BM + 2 * halo + 1) * (HBK + 8) + (size_t)3 * 128 * HLD) * 2;
     const size_t epi = (size_t)BM * (128 + 4) * 4;
     return loop > epi ? loop : epi;
 }
@@ -1506,7 +1519,7 @@ static hipError_t try_gemm_bf16_ar(const GemmParams& p, hipStream_t s, bool* use
         return launch_gemm_bf16_ar_t<256, 4, 2, 3, 3, 0, true>(p, s);
     }
 #define GAR_CASE(BM_, WM_, WN_, BD_) if (bm == BM_ && wm == WM_ && wn == WN_ && bd == BD_) return launch_gemm_bf16_ar_t<BM_, WM_, WN_, 3, BD_>(p, s);
-    GAR_CASE(256, 4, 2, 3) GAR_CASE(128, 2, 2, 3) GAR_CASE(128, 2, 2, 1) GAR_CASE(128, 4, 2, 3) GAR_CASE(256, 4, 2, 1)
+    GAR_CASE(256, 4, 2, 3) GAR_CASE(128, 2, 2, 3) GAR_CASE(128, 4, 2, 3)
 #undef GAR_CASE
     *used = false;
     return hipSuccess;

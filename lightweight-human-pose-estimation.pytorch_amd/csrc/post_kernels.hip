@@ -541,6 +541,101 @@ __global__ void __launch_bounds__(256) find_peaks_kernel(MapView heat, PostWorks
         }
     }
 }
+// Column form for the up-sampled maps at large batches (R = 4 | 8): tile = 32 rows x 62 columns, lane = one full-resolution
+// COLUMN X0 - 1 + lane (lanes 0 and 63 are the halo columns), wave w = output rows 8w .. 8w + 7 of the tile.  After the
+// horizontal pass (as above, through LDS) a thread reads its column's 5-6 horizontal values ONCE and keeps the ten up-sampled
+// values of its rows (8 + the row above and below) in registers: up / down neighbours are registers, left / right ones come
+// from the neighbouring lanes (DPP wave shifts) — no full-resolution tile in LDS, no per-pixel index arithmetic, two barriers
+// instead of four.  The tile's first row is a multiple of R, so the phase of every row and its taps are compile-time constants.
+// Same products and sums in the same order as sample_map: the same bits (peaks are appended in any order; nms_kernel sorts).
+template <int R>
+__global__ void __launch_bounds__(256) find_peaks_cols_kernel(MapView heat, PostWorkspace ws) {
+    constexpr int PTH = 32, PTW = 62, RG = 8;
+    constexpr int LH = PTH / R + 6, LW = 64 / R + 6;
+    __shared__ float lo[LH][LW + 1];
+    __shared__ float hz[LH][64];
+    const int Hf = heat.h * R, Wf = heat.w * R;
+    const int tiles_x = (Wf + PTW - 1) / PTW;
+    const int X0 = (blockIdx.x % tiles_x) * PTW, Y0 = (blockIdx.x / tiles_x) * PTH;
+    const int t = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* base = heat.base + (int64_t)n * heat.ns + (int64_t)t * heat.cs;
+    if (blockIdx.x == 0 && t == 0 && tid < 4)   // flags are only touched by the kernels that follow in the stream
+        ws.flags[n * 4 + tid] = (tid == 1 || tid == 2) ? ~0ull : 0ull;
+    const CubicTable& ct = g_cubic[R == 4 ? 0 : 1];
+    const int ly0 = Y0 / R - 3;
+    const int lx0 = X0 == 0 ? -3 : (X0 - 1) / R - 2;              // first tap column of the left halo column
+    for (int i = tid; i < LH * LW; i += 256) {
+        const int j = i / LW, k = i % LW;
+        lo[j][k] = base[(int64_t)clampi(ly0 + j, 0, heat.h - 1) * heat.ys + (int64_t)clampi(lx0 + k, 0, heat.w - 1) * heat.xs];
+    }
+    __syncthreads();
+    const int X = X0 - 1 + lane;
+    const bool x_ok = X >= 0 && X < Wf;
+    {
+        const int Xc = x_ok ? X : 0;
+        const int qx = Xc / R, px = Xc - qx * R;
+        const int c = qx + ct.off[px] - 1 - lx0;                   // patch column of the first tap
+        const float w0 = ct.w[px][0], w1 = ct.w[px][1], w2 = ct.w[px][2], w3 = ct.w[px][3];
+        for (int j = wave; j < LH; j += 4) {                       // horizontal pass
+            float a = __fmul_rn(lo[j][c], w0);
+            a = __fadd_rn(a, __fmul_rn(lo[j][c + 1], w1));
+            a = __fadd_rn(a, __fmul_rn(lo[j][c + 2], w2));
+            a = __fadd_rn(a, __fmul_rn(lo[j][c + 3], w3));
+            hz[j][lane] = x_ok ? a : 0.f;
+        }
+    }
+    __syncthreads();
+    // rows Y0 + 8 wave - 1 + k, k = 0 .. 9: phase py(k) = (k - 1) mod R, low-res row (k - 1) div R, first tap row idx(k) relative to
+    // the patch row of the wave's first output row
+    auto fdiv = [](int a, int b) constexpr { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    auto idx = [&](int k) constexpr { const int q = fdiv(k - 1, R), py = k - 1 - q * R; return q + (py < R / 2 ? -1 : 0) - 1; };
+    constexpr int IMIN = -2;                                       // idx(0): the row above the first one (phase R - 1, tap rows -2 .. 1)
+    const int IMAX = idx(RG + 1);
+    constexpr int NV = (R == 4 ? 0 : -1) - IMIN + 4;               // idx(9) = 0 (R = 4) | -1 (R = 8)
+    (void)IMAX;
+    float hv[NV];
+    const int r0 = 3 + wave * (RG / R) + IMIN;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) hv[j] = hz[r0 + j][lane];
+    float val[RG + 2];
+    const int Yw = Y0 + wave * RG - 1;
+#pragma unroll
+    for (int k = 0; k < RG + 2; ++k) {
+        const int q = fdiv(k - 1, R), py = k - 1 - q * R;
+        const int o = q + (py < R / 2 ? -1 : 0) - 1 - IMIN;       // compile-time
+        float v = __fmul_rn(hv[o], ct.w[py][0]);
+        v = __fadd_rn(v, __fmul_rn(hv[o + 1], ct.w[py][1]));
+        v = __fadd_rn(v, __fmul_rn(hv[o + 2], ct.w[py][2]));
+        v = __fadd_rn(v, __fmul_rn(hv[o + 3], ct.w[py][3]));
+        const int Y = Yw + k;
+        val[k] = (x_ok && Y >= 0 && Y < Hf && !(v < 0.1f)) ? v : 0.f;
+    }
+    const int slot = n * gridDim.y + t;
+#pragma unroll
+    for (int k = 1; k <= RG; ++k) {
+        const float c = val[k];
+        const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x138, 0xf, 0xf, false));    // wave_shr:1
+        const float right = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x130, 0xf, 0xf, false));   // wave_shl:1
+        const int Y = Yw + k;
+        if (lane >= 1 && lane <= PTW && X < Wf && Y < Hf && c > right && c > left && c > val[k + 1] && c > val[k - 1]) {
+            const int pos = atomicAdd(&ws.peak_count[slot], 1);
+            if (pos < ws.caps.max_peaks) {
+                ws.peak_key[(int64_t)slot * ws.caps.max_peaks + pos] = ((uint32_t)X << 16) | (uint32_t)Y;
+                ws.peak_val[(int64_t)slot * ws.caps.max_peaks + pos] = c;
+            }
+        }
+    }
+}
+template <int R>
+static hipError_t launch_find_peaks_cols(const MapView& heat, int N, int ntypes, PostWorkspace& ws, hipStream_t s) {
+    const int Hf = heat.h * R, Wf = heat.w * R;
+    const int tiles = ((Wf + 61) / 62) * ((Hf + 31) / 32);
+    hipLaunchKernelGGL((find_peaks_cols_kernel<R>), dim3(tiles, ntypes, N), dim3(256), 0, s, heat, ws);
+    return hipGetLastError();
+}
+
 template <int PTH, int PTW>
 static hipError_t launch_find_peaks_t(const MapView& heat, int N, int ntypes, int ratio, PostWorkspace& ws, hipStream_t s) {
     const int Hf = heat.h * ratio, Wf = heat.w * ratio;
@@ -558,8 +653,11 @@ hipError_t launch_find_peaks(const MapView& heat, int N, int ntypes, int ratio, 
     const Tuning& T = tune ? *tune : default_tuning();
     const int Hf = heat.h * ratio, Wf = heat.w * ratio;
     const int64_t wgs = (int64_t)((Wf + 31) / 32) * ((Hf + 15) / 16) * ntypes * N;
-    int sel = wgs >= 16384 ? 3 : 0;
-    if (T.peak_tile >= 0) sel = T.peak_tile;                      // LWP_PEAK_TILE 0..3 (A/B)
+    int sel = ratio != 1 ? 4 : (wgs >= 16384 ? 3 : 0);            // up-sampled maps: the column form (49 / 17.8 / 8.3 us at batch 32 / 8 / 1 against 78 / 33.5 / 9.8 for the tiles)
+    if (T.peak_tile >= 0) sel = T.peak_tile;                      // LWP_PEAK_TILE 0..4 (A/B; 4 = the column form)
+    if (sel == 4 && ratio == 4) return launch_find_peaks_cols<4>(heat, N, ntypes, ws, s);
+    if (sel == 4 && ratio == 8) return launch_find_peaks_cols<8>(heat, N, ntypes, ws, s);
+    if (sel == 4) sel = 3;
     if (sel == 1) return launch_find_peaks_t<32, 32>(heat, N, ntypes, ratio, ws, s);
     if (sel == 2) return launch_find_peaks_t<16, 64>(heat, N, ntypes, ratio, ws, s);
     if (sel == 3) return launch_find_peaks_t<32, 64>(heat, N, ntypes, ratio, ws, s);

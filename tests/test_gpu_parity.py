@@ -287,6 +287,33 @@ def test_post_fused_from_maps_matches_reference_golden(eng, name):
         assert np.array_equal(ent.reshape(-1, 20), g[tag + "_entries"].reshape(-1, 20))
 
 
+@pytest.mark.parametrize("name", POST)
+def test_post_column_form_peak_finder_matches_reference_golden(monkeypatch, name):
+    """find_peaks_cols_kernel (the large-batch form: lane = one full-resolution column, ten up-sampled values of the thread's rows in
+    registers, left / right neighbours through DPP wave shifts, 32 x 62 tiles) forced at the golden sizes — 184 x 328, 96 x 128,
+    128 x 192 at ratio 4 and 8: widths that are no multiple of 62, heights that are no multiple of 32 — must give the reference's
+    key-points and poses bit for bit, alone and as frames 0 and 2 of a batch of three."""
+    monkeypatch.setenv("LWP_PEAK_TILE", "4")
+    e4 = Engine(0)
+    g = np.load(os.path.join(GOLDEN, "post_%s.npz" % name))
+    n, h, w, seed, ratio = [int(v) for v in g["params"]]
+    heat, paf, _ = synth.make_pose_maps(n, h, w, seed, float(g["drop"]), float(g["noise"]))
+    heat3 = np.stack([heat, heat[:, ::-1].copy(), heat])
+    paf3 = np.stack([paf, paf[:, ::-1].copy(), paf])
+    for tag, demo in (("demo", True), ("val", False)):
+        gk = g[tag + "_kp"]
+        for res in (e4.poses_from_maps(heat[None], paf[None], ratio, demo)[0], e4.poses_from_maps(heat3, paf3, ratio, demo)[0],
+                    e4.poses_from_maps(heat3, paf3, ratio, demo)[2]):
+            ent, allk, counts = res
+            assert np.array_equal(allk, g[tag + "_allk"].reshape(-1, 4))
+            assert np.array_equal(counts, np.bincount(gk[:, 4].astype(int), minlength=18) if len(gk) else np.zeros(18, int))
+            assert np.array_equal(ent.reshape(-1, 20), g[tag + "_entries"].reshape(-1, 20))
+    monkeypatch.setenv("LWP_PEAK_TILE", "0")
+    e0 = Engine(0)
+    a, b = e4.poses_from_maps(heat3, paf3, ratio, True)[1], e0.poses_from_maps(heat3, paf3, ratio, True)[1]
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))                       # the flipped frame too
+
+
 def test_group_adversarial_golden(eng):
     g = np.load(os.path.join(GOLDEN, "group_adversarial.npz"))
     for nm in [k[4:] for k in g.files if k.startswith("paf:")]:
