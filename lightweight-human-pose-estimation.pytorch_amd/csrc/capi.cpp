@@ -41,6 +41,10 @@ struct lwp_context {
     std::vector<ResizeTab> scale_tabs;                   // image-side tables of lwp_preprocess_scaled_u8: (W, H, dw, dh, ratio)
     unsigned char* d_imgs = nullptr; size_t d_imgs_bytes = 0;   // uint8 frame batch staging (host frames of the multi-scale path)
     float* d_img = nullptr; size_t d_img_bytes = 0;     // uint8 frame staging (pre-processing of host frames)
+    // host frames travel through one of two pinned buffers (upload_host): a copy from pageable memory is staged by the runtime
+    // anyway, at ~100 us per 720 KB frame and with the calling thread blocked until the DMA has finished
+    void* pin_buf[2] = {nullptr, nullptr}; size_t pin_bytes[2] = {0, 0}; hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_busy[2] = {false, false};
+    int pin_next = 0;
     float* d_pre_tab = nullptr; size_t d_pre_tab_bytes = 0;   // fixed-point resize tables, cached for (pre_H, pre_W, pre_net_h)
     int pre_H = 0, pre_W = 0, pre_net_h = 0;
     float* d_maps[2] = {nullptr, nullptr}; size_t d_maps_bytes[2] = {0, 0};   // bf16 path: f32 NCHW heat / PAF of the last stage
@@ -238,6 +242,10 @@ extern "C" int lwp_destroy(lwp_handle h) {
     for (auto& rt : h->scale_tabs) if (rt.d) (void)hipFree(rt.d);
     if (h->d_imgs) (void)hipFree(h->d_imgs);
     if (h->d_img) (void)hipFree(h->d_img);
+    for (int k = 0; k < 2; ++k) {
+        if (h->pin_buf[k]) (void)hipHostFree(h->pin_buf[k]);
+        if (h->pin_ev[k]) (void)hipEventDestroy(h->pin_ev[k]);
+    }
     if (h->d_pre_tab) (void)hipFree(h->d_pre_tab);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_zeros) (void)hipFree(h->d_zeros);
@@ -797,6 +805,37 @@ extern "C" int lwp_preprocess_dims(int H, int W, int net_input_height, int strid
     return LWP_OK;
 }
 
+// Host frames -> the device buffer `dst` on the handle's stream.  Up to kPinLimit bytes: memcpy (calling thread) into one of two
+// pinned staging buffers, then an asynchronous DMA — the caller's buffer is free when this returns (*consumed = true) and the
+// call need not wait for the copy; the staging buffer is reused only after the DMA that read it has finished (its event).
+// Larger batches: a plain asynchronous copy from the caller's memory (*consumed = false: the caller must wait for ev_copy).
+constexpr size_t kPinLimit = (size_t)64 << 20;
+static int upload_host(lwp_context* h, const void* src, size_t bytes, void* dst, bool* consumed) {
+    *consumed = false;
+    if (bytes <= kPinLimit) {
+        const int k = h->pin_next;
+        h->pin_next ^= 1;
+        if (h->pin_busy[k]) { HIP_TRY(h, hipEventSynchronize(h->pin_ev[k])); h->pin_busy[k] = false; }
+        if (h->pin_bytes[k] < bytes) {
+            if (h->pin_buf[k]) HIP_TRY(h, hipHostFree(h->pin_buf[k]));
+            h->pin_buf[k] = nullptr; h->pin_bytes[k] = 0;
+            HIP_TRY(h, hipHostMalloc(&h->pin_buf[k], bytes, hipHostMallocDefault));
+            h->pin_bytes[k] = bytes;
+        }
+        if (!h->pin_ev[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->pin_ev[k], hipEventDisableTiming));
+        std::memcpy(h->pin_buf[k], src, bytes);
+        HIP_TRY(h, hipMemcpyAsync(dst, h->pin_buf[k], bytes, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipEventRecord(h->pin_ev[k], h->stream));
+        h->pin_busy[k] = true;
+        *consumed = true;
+        return LWP_OK;
+    }
+    if (!h->ev_copy) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
+    HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev_copy, h->stream));
+    return LWP_OK;
+}
+
 extern "C" int lwp_preprocess_u8(lwp_handle h, const unsigned char* img, int img_mem, int H, int W, int net_input_height,
                                  int stride, const double* pad_value, const double* img_mean, double img_scale, float* out_device) {
     if (!h || !img || !pad_value || !img_mean || !out_device) return fail(h, LWP_ERR_ARG, "null argument");
@@ -809,13 +848,13 @@ extern "C" int lwp_preprocess_u8(lwp_handle h, const unsigned char* img, int img
     rc = order_in(h);                                    // device frame produced / output buffer last used on the caller's stream
     if (rc) return rc;
     const unsigned char* d_src = img;
+    bool consumed = false;
     if (img_mem == LWP_MEM_HOST) {
         const size_t ib = (size_t)H * W * 3;
         rc = ensure_dev(h, &h->d_img, &h->d_img_bytes, ib);
         if (rc) return rc;
-        if (!h->ev_copy) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
-        HIP_TRY(h, hipMemcpyAsync(h->d_img, img, ib, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipEventRecord(h->ev_copy, h->stream));
+        rc = upload_host(h, img, ib, h->d_img, &consumed);
+        if (rc) return rc;
         d_src = (const unsigned char*)h->d_img;
     }
     const size_t nx = (size_t)dw * 4, ny = (size_t)dh * 4;
@@ -845,11 +884,12 @@ extern "C" int lwp_preprocess_u8(lwp_handle h, const unsigned char* img, int img
     bool ordered = false;
     rc = order_out(h, h->stream, &ordered);
     if (rc) return rc;
-    // the caller may reuse its host frame buffer on return: wait for the COPY only; the kernel's output is stream-ordered
-    // (consumed by this handle's next call, or by the caller's stream after the event hand-over)
+    // the caller may reuse its host frame buffer on return: it has been copied into the pinned staging buffer already (or, for
+    // very large frames, the COPY is waited for); the kernel's output is stream-ordered (consumed by this handle's next call, or
+    // by the caller's stream after the event hand-over).  Without a declared caller stream the call completes on return.
     if (img_mem == LWP_MEM_HOST) {
-        if (ordered) HIP_TRY(h, hipEventSynchronize(h->ev_copy));
-        else HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (!ordered) HIP_TRY(h, hipStreamSynchronize(h->stream));
+        else if (!consumed) HIP_TRY(h, hipEventSynchronize(h->ev_copy));
     }
     return LWP_OK;
 }
@@ -902,6 +942,7 @@ static int preprocess_scaled_impl(lwp_handle h, const void* imgs, int elem, int 
     rc = order_in(h);
     if (rc) return rc;
     const void* d_src = imgs;
+    bool consumed = false;
     if (img_mem == LWP_MEM_HOST) {
         const size_t ib = (size_t)N * H * W * 3 * elem;
         if (h->d_imgs_bytes < ib) {
@@ -911,9 +952,8 @@ static int preprocess_scaled_impl(lwp_handle h, const void* imgs, int elem, int 
             HIP_TRY(h, hipMalloc((void**)&h->d_imgs, ib));
             h->d_imgs_bytes = ib;
         }
-        if (!h->ev_copy) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
-        HIP_TRY(h, hipMemcpyAsync(h->d_imgs, imgs, ib, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipEventRecord(h->ev_copy, h->stream));
+        rc = upload_host(h, imgs, ib, h->d_imgs, &consumed);
+        if (rc) return rc;
         d_src = h->d_imgs;
     }
     const size_t nx = (size_t)dw * 4, ny = (size_t)dh * 4;
@@ -951,7 +991,7 @@ static int preprocess_scaled_impl(lwp_handle h, const void* imgs, int elem, int 
     rc = order_out(h, h->stream, &ordered);
     if (rc) return rc;
     if (!ordered) HIP_TRY(h, hipStreamSynchronize(h->stream));                    // no declared caller stream: complete on return
-    else if (img_mem == LWP_MEM_HOST) HIP_TRY(h, hipEventSynchronize(h->ev_copy));   // host frames may be reused: the copy only
+    else if (img_mem == LWP_MEM_HOST && !consumed) HIP_TRY(h, hipEventSynchronize(h->ev_copy));   // host frames may be reused: the copy only
     return LWP_OK;
 }
 
