@@ -104,6 +104,7 @@ struct Tuning {
     int upsample_tiled = -1;                                       // LWP_UPSAMPLE_TILED
     int max_frames_per_pass = 0;                                   // LWP_MAX_FRAMES_PER_PASS (tests: split batches as if the 2 GiB limit were reached earlier)
     int peak_tile = -1, pair_form = -1;                            // LWP_PEAK_TILE (find_peaks tile 0..3), LWP_PAIR_FORM (score_pairs variant)
+    int dwpw_lds_pad_kb = 0;                                       // LWP_DWPW_LDS_PAD (KB of unused LDS per workgroup of the bf16 fused blocks: occupancy experiments)
     int post_nchw = -1;                                            // LWP_POST_NCHW (f32: "0" = grouping reads the NHWC concat buffer in place)
     int heads_f32_max_m = 0;                                       // LWP_HEADS_F32_MAXM (tests: force the fused fp32 head pair at larger M)
 };

@@ -1137,6 +1137,11 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
 //            never touches LDS: it is packed on the host in fragment order [k-step][wave][4][lane][4 floats], so each
 //            wave streams its own 4 KiB per 32-deep step from L2 with four fully coalesced 1-KiB loads, prefetched
 //            one step ahead in registers.  With 4 waves per SIMD and no barrier the matrix pipes stay fed.
+// Row padding of the f32 depthwise tile [rows][C + 4].  The K loop's operand read (one ds_read_b128 per lane at row = lane & 15,
+// 16 bytes x (lane >> 4)) is two-way bank-conflicted with this stride (16 B x odd) and conflict-free with C + 8 — measured: the
+// f32 blocks do not care (the f32 MFMA leaves the LDS idle most of the time): 26.9 against 26.2 us at batch 1 with C + 8, the
+// same at batch 32.  The bf16 kernels take the conflict-free stride (DWPW_APAD, net_kernels_bf16.hip).
+constexpr int DWPW_F32_APAD = 4;
 template <int BM, int NW, int DBG = 0, int ACT = -1>
 __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
     // ACT >= 0: both activations known at compile time (ReLU for every conv_dw block): no chain of scalar branches per vector
@@ -1144,8 +1149,8 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
     constexpr int NT = NW * 64;
     constexpr int RT = BM / 16;                      // row tiles per wave
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    const int ldA = p.C + 4;                         // padded row stride (floats)
-    float* At = dsm;                                 // [BM][C + 4]
+    const int ldA = p.C + DWPW_F32_APAD;             // padded row stride (floats)
+    float* At = dsm;                                 // [BM][C + DWPW_F32_APAD]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = blockIdx.y * NW + (tid >> 6);   // global column-wave index (blockIdx.y: column split)
@@ -1335,7 +1340,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_kernel(DwPwParams p) {
 template <int BM, int NW, int DBG = 0, int ACT = -1>
 static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
-    const size_t lds = (size_t)BM * (p.C + 4) * sizeof(float);
+    const size_t lds = (size_t)BM * (p.C + DWPW_F32_APAD) * sizeof(float);
     if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 4 >= (1ll << 31)) return hipErrorInvalidValue;     // 32-bit buffer offsets (2 GiB of input per launch)
     const int nsplit = (p.cout / 32) / NW;
     static LdsAttrOnce attr;
@@ -1361,7 +1366,7 @@ static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t s) {
 template <int C>     // depthwise channels (256 | 512); 512 output channels = 16 waves x 32
 __global__ void __launch_bounds__(1024) dwpw_pipe_kernel(DwPwParams p, int ntiles) {
     constexpr int BM = 32, NT = 1024, RT = BM / 16, NSTEP = C / 32;
-    constexpr int ldA = C + 4;
+    constexpr int ldA = C + DWPW_F32_APAD;
     constexpr int CG = C / 4;                        // 4-channel chunks per pixel
     constexpr int PAR = NT / CG;                     // pixels in flight across the workgroup (8 | 16)
     constexpr int NIT = BM / PAR;                    // pixels per thread and tile (4 | 2)
@@ -1486,7 +1491,7 @@ template <int C>
 static hipError_t launch_dwpw_pipe_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     const int ntiles = (int)((M + 31) / 32);
-    const size_t lds = (size_t)(2 * 32 * (C + 4) + 10 * C) * sizeof(float);
+    const size_t lds = (size_t)(2 * 32 * (C + DWPW_F32_APAD) + 10 * C) * sizeof(float);
     static LdsAttrOnce attr;
     hipError_t e = attr.ensure((const void*)dwpw_pipe_kernel<C>, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -1550,7 +1555,7 @@ hipError_t launch_dwpw(const DwPwParams& p_in, hipStream_t s) {
     if (T.dwpw_bm) bm = T.dwpw_bm;                   // LWP_DWPW_BM
     if (T.dwpw_nw > 0 && T.dwpw_nw < nw && nw % T.dwpw_nw == 0) nw_wg = T.dwpw_nw;   // LWP_DWPW_NW
     if (bm > 64) bm = 64;
-    while (bm > 16 && (size_t)bm * (p.C + 4) * sizeof(float) > 150 * 1024) bm >>= 1;
+    while (bm > 16 && (size_t)bm * (p.C + DWPW_F32_APAD) * sizeof(float) > 150 * 1024) bm >>= 1;
     LWP_VARIANT(p, "dwpw<%d,%d>", bm, nw_wg);
 #ifdef LWP_ABLATION
     const int d = T.dwpw_debug;
@@ -1735,7 +1740,7 @@ Tuning tuning_from_env() {
     geti("LWP_GEMMH_DEBUG", &t.gemmh_debug);
     if (const char* e = getenv("LWP_GEMMH")) t.has_gemmh = sscanf(e, "%d,%d,%d,%d", &t.gemmh[0], &t.gemmh[1], &t.gemmh[2], &t.gemmh[3]) == 4;
     digit("LWP_UPSAMPLE_TILED", &t.upsample_tiled);
-    digit("LWP_PEAK_TILE", &t.peak_tile); digit("LWP_PAIR_FORM", &t.pair_form); digit("LWP_POST_NCHW", &t.post_nchw);
+    digit("LWP_PEAK_TILE", &t.peak_tile); digit("LWP_PAIR_FORM", &t.pair_form); digit("LWP_POST_NCHW", &t.post_nchw); geti("LWP_DWPW_LDS_PAD", &t.dwpw_lds_pad_kb);
     geti("LWP_HEADS_F32_MAXM", &t.heads_f32_max_m);
     geti("LWP_MAX_FRAMES_PER_PASS", &t.max_frames_per_pass);
     return t;

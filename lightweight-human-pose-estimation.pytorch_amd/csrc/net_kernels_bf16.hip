@@ -47,6 +47,15 @@ static int device_cu_count() {
 // A lane (i = lane&15, q = lane>>4) reads 8 consecutive k (16 B) at k = 32s + 8q: exactly the operand lane map, for
 // the activation tile (from LDS) and for the fragment-packed weights [k-step][wave][tile][lane][8] (from L2) alike.
 // DBG (compile time; LWP_ABLATION builds only): 1 no depthwise phase, 2 no weight stream, 4 no MFMA, 8 no epilogue
+// Row padding of the depthwise tile [rows][C + DWPW_APAD] (bf16): the K loop's operand read is one ds_read_b128 per lane at
+// (row = lane & 15, 16 bytes x (lane >> 4)), served in four groups of 16 lanes (MI355X_MICROARCH.md, LDS): the 16 lanes of a group
+// must land on 16 different 16-byte bank slots.  With rows of C + 8 elements (stride = 16 B x 17 mod 256) every group holds one
+// pair on the same slot — a two-way conflict on EVERY operand read (rocprofv3: SQ_LDS_BANK_CONFLICT = 46-48 % of SQ_LDS_IDX_ACTIVE
+// in these kernels); C + 16 (stride = 16 B x 2 mod 256) is conflict-free.
+constexpr int DWPW_APAD = 16;
+// (The depthwise weights' reads — two 16-byte reads per lane, lanes 32 bytes apart — are two-way conflicted too; a split
+//  [low halves | high halves] layout removes that but needs a second run-time address per tap: +18 VGPRs, a wave of occupancy
+//  lost on the 4-wave kernels, spills on the dilation-2 one — measured slower and dropped.)
 template <int BM, int NW, int DBG = 0, int SDIL = 1, int ACT = -1>
 __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     // ACT >= 0: both activations known at compile time (ReLU for every conv_dw block) — with the run-time switch every output
@@ -55,8 +64,8 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     constexpr int NT = NW * 64;
     constexpr int RT = BM / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
-    __bf16* At = (__bf16*)dsm_raw;                   // [BM][C + 8]
-    const int ldA = p.C + 8;
+    __bf16* At = (__bf16*)dsm_raw;                   // [BM][C + DWPW_APAD]
+    const int ldA = p.C + DWPW_APAD;
     const __bf16* in = (const __bf16*)p.in;
     const __bf16* pw = (const __bf16*)p.pw_w;
 
@@ -100,7 +109,7 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
     constexpr int PXG = 2;                           // a 3 x 4 window of 16-byte vectors: fits the 128-VGPR cap of the 16-wave workgroups
     static_assert(BM % PXG == 0, "row block must hold whole pixel groups");
     constexpr int WC_ = NW * 32;
-    const int wd_off = ((BM * (p.C > WC_ ? p.C + 8 : WC_ + 8) * 2) + 15) & ~15;
+    const int wd_off = ((BM * (p.C + DWPW_APAD > WC_ + 8 ? p.C + DWPW_APAD : WC_ + 8) * 2) + 15) & ~15;
     float* Wd = (float*)(dsm_raw + wd_off);          // [10][C]
     for (int i = tid * 4; i < 10 * p.C; i += NT * 4) *(f32x4*)(Wd + i) = *(const f32x4*)(p.dw_w + i);
     __syncthreads();
@@ -296,10 +305,11 @@ __global__ void __launch_bounds__(NW * 64) dwpw_bf16_kernel(DwPwParams p) {
 template <int BM, int NW, int DBG = 0, int SDIL = 1, int ACT = -1>
 static hipError_t launch_dwpw_bf16_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
-    size_t lds = (size_t)BM * (p.C + 8) * 2;
+    size_t lds = (size_t)BM * (p.C + DWPW_APAD) * 2;
     const size_t lds_out = (size_t)BM * (NW * 32 + 8) * 2;          // the staged output tile re-uses the space
     if (lds_out > lds) lds = lds_out;
     lds = ((lds + 15) & ~(size_t)15) + (size_t)10 * p.C * sizeof(float);   // + the depthwise weights and bias
+    if (p.tune && p.tune->dwpw_lds_pad_kb > 0) lds += (size_t)p.tune->dwpw_lds_pad_kb * 1024;      // LWP_DWPW_LDS_PAD (experiments: fewer workgroups per CU)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if ((int64_t)p.N * p.Hi * p.Wi * p.in_ld * 2 >= (1ll << 31) || (p.C & 7)) return hipErrorInvalidValue;   // 32-bit buffer offsets, 8-channel lanes
     const int nsplit = (p.cout / 32) / NW;
@@ -327,7 +337,7 @@ template <int NCT, int ACT, int SDIL>      // NCT: 16-channel column tiles per K
 __global__ void __launch_bounds__(1024) dwpw_bf16_pp_kernel(DwPwParams p, int n_half) {
     constexpr int HB = 64, RT = HB / 16, GT = 512;       // pixels per half-tile, row tiles, threads per wave group
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm_raw[];
-    const int ldA = p.C + 8;
+    const int ldA = p.C + DWPW_APAD;
     const __bf16* in = (const __bf16*)p.in;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -506,7 +516,7 @@ template <int NCT, int ACT, int SDIL>
 static hipError_t launch_dwpw_bf16_pp_t(const DwPwParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
     const int n_half = (int)((M + 63) / 64);
-    const size_t lds = (((size_t)2 * 64 * (p.C + 8) * 2 + 15) & ~(size_t)15) + (size_t)10 * p.C * sizeof(float);
+    const size_t lds = (((size_t)2 * 64 * (p.C + DWPW_APAD) * 2 + 15) & ~(size_t)15) + (size_t)10 * p.C * sizeof(float);
     static LdsAttrOnce attr;
     hipError_t e = attr.ensure((const void*)dwpw_bf16_pp_kernel<NCT, ACT, SDIL>, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -535,7 +545,7 @@ static hipError_t try_dwpw_bf16_pp(const DwPwParams& p, hipStream_t s, bool* use
     if (!(p.act_dw == ACT_RELU && p.act_pw == ACT_RELU)) return hipSuccess;
     if ((p.out_ld & 7) || (((uintptr_t)p.out) & 15) || (p.in_ld & 7)) return hipSuccess;
     if (M >= (1ll << 31) - 128 || (int64_t)p.N * p.Hi * p.Wi * p.in_ld * 2 >= (1ll << 31)) return hipSuccess;
-    if ((size_t)2 * 64 * (p.C + 8) * 2 + 16 + (size_t)40 * p.C > 160 * 1024) return hipSuccess;
+    if ((size_t)2 * 64 * (p.C + DWPW_APAD) * 2 + 16 + (size_t)40 * p.C > 160 * 1024) return hipSuccess;
     *used = true;
     LWP_VARIANT(p, "dwpw_bf16_pp<%d,dil=%d>", p.cout / 128, p.dil);
     DwPwParams q = p;
@@ -574,7 +584,7 @@ hipError_t launch_dwpw_bf16(const DwPwParams& p_in, hipStream_t s) {
     if (M / 64 >= 1024 && nw >= 8) bm = 128;         // >= 256 output channels: halve the per-workgroup weight stream (measured 3-8 %)
     const Tuning& T = p.tune ? *p.tune : default_tuning();
     if (T.dwpw_bm) bm = T.dwpw_bm;                   // LWP_DWPW_BM
-    while (bm > 16 && (size_t)bm * ((p.C > p.cout ? p.C : p.cout) + 8) * 2 + (size_t)40 * p.C + 16 > 160 * 1024) bm >>= 1;
+    while (bm > 16 && (size_t)bm * (p.C + DWPW_APAD > p.cout + 8 ? p.C + DWPW_APAD : p.cout + 8) * 2 + (size_t)40 * p.C + 16 > 160 * 1024) bm >>= 1;
     if (bm == 128 && nw < 4) bm = 64;
     // every thread must own a whole 8-channel chunk column: NW*64 threads must be a multiple of C/8 (always true here)
     LWP_VARIANT(p, "dwpw_bf16<%d,%d,dil=%d>", bm, nw, (nw == 16 && p.dil == 2 && p.stride == 1) ? 2 : 1);

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256, 3) dwpw_tiled_kernel(DwPwParams p, int ti
     constexpr int WR = (PH - 1) * S + 3, WC = (PW - 1) * S + 3;
     constexpr int NPX = PH * PW;                        // output pixels of the patch
     constexpr int RT = NPX / 16;                        // MFMA row tiles
-    constexpr int LDT = C + (BF16 ? 8 : 4);             // operand tile row stride (elements): conflict-free ds_read_b128
+    constexpr int LDT = C + (BF16 ? 16 : 4);            // operand tile row stride (elements); bf16: +32 B = conflict-free ds_read_b128 (rows of +16 B are two-way conflicted; f32 does not care)
     constexpr int NU = COUT / 32;                       // 32-channel output units
     constexpr int WCOLS = NU < 4 ? NU : 4;              // waves across the output channels
     constexpr int WROWS = 4 / WCOLS;                    // waves across the row tiles
@@ -280,7 +280,7 @@ template <bool BF16, int C, int COUT, int S, int PH, int ACT = ACT_RELU>
 static hipError_t launch_tiled_t(const DwPwParams& p, hipStream_t s) {
     constexpr int ESZ = BF16 ? 2 : 4;
     constexpr int WR = (PH - 1) * S + 3, WC = 7 * S + 3;
-    constexpr size_t win = (size_t)WR * WC * C * ESZ, til = (size_t)PH * 8 * (C + (BF16 ? 8 : 4)) * ESZ;
+    constexpr size_t win = (size_t)WR * WC * C * ESZ, til = (size_t)PH * 8 * (C + (BF16 ? 16 : 4)) * ESZ;
     constexpr size_t lds = (((win > til ? win : til) + 15) & ~(size_t)15) + (size_t)10 * C * sizeof(float);
     const int tiles_y = (p.Ho + PH - 1) / PH, tiles_x = (p.Wo + 7) / 8;
     const int64_t tiles = (int64_t)p.N * tiles_y * tiles_x;
