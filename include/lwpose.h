@@ -241,6 +241,11 @@ int lwp_debug_layer_variant(lwp_handle h, int layer_index, char* name, int name_
 /* frames one launch sequence of an N x 3 x H x W call takes (N unless a tensor of the pass would reach the kernels' 2 GiB
  * addressing range: lwp_forward / lwp_infer_poses* / lwp_pipeline_submit then walk the batch in equal chunks of this size) */
 int lwp_debug_frames_per_pass(lwp_handle h, int N, int H, int W);
+/* intermediate counts of the grouping kernels for frame `frame` of the handle's LAST lwp_infer_poses / lwp_infer_poses_async /
+ * lwp_poses_from_maps call (after its results were fetched): candidate peaks per key-point type before the NMS [18], key-points per
+ * type after it [18], scored connection candidates per limb [19], connections picked per limb [19].  Tests / tools: which
+ * form of nms_kernel / match_kernel (register form up to 64 candidates, LDS form beyond) a workload exercises. */
+int lwp_debug_post_counts(lwp_handle h, int frame, int* peaks18, int* kpts18, int* candidates19, int* picked19);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ EXPORTS = [
     "lwp_infer_poses", "lwp_infer_poses_async", "lwp_fetch_poses", "lwp_time_pipeline", "lwp_profile_classes",
     "lwp_synchronize", "lwp_poses_from_maps", "lwp_layer_count", "lwp_layer_info", "lwp_debug_layer_output",
     "lwp_profile_launches", "lwp_debug_time_layer", "lwp_pipeline_submit", "lwp_pipeline_fetch", "lwp_multiscale_accumulate",
-    "lwp_preprocess_dims", "lwp_preprocess_u8", "lwp_scale_dims", "lwp_preprocess_scaled_u8", "lwp_debug_layer_variant", "lwp_set_stream", "lwp_preprocess_scaled_f32", "lwp_debug_frames_per_pass",
+    "lwp_preprocess_dims", "lwp_preprocess_u8", "lwp_scale_dims", "lwp_preprocess_scaled_u8", "lwp_debug_layer_variant", "lwp_set_stream", "lwp_preprocess_scaled_f32", "lwp_debug_frames_per_pass", "lwp_debug_post_counts",
 ]
 
 
@@ -78,6 +78,7 @@ def lib():
     L.lwp_debug_layer_variant.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
     L.lwp_set_stream.argtypes = [vp, vp, C.c_int]
     L.lwp_debug_frames_per_pass.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.lwp_debug_post_counts.argtypes = [vp, C.c_int] + [C.POINTER(C.c_int)] * 4
     for name in EXPORTS:
         if name not in ("lwp_last_error",):
             getattr(L, name).restype = C.c_int

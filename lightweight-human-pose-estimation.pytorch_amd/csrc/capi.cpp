@@ -222,7 +222,7 @@ static void free_ws_obj(PostWorkspace& w) {
     // flags / kpt_count / n_entries / kpts_out / entries live in ONE allocation (result_block) so the fetch is one copy
     void* ptrs[] = {w.peak_count, w.peak_key, w.peak_val, w.kpt_xy, w.kpt_score, w.conn_count,
                     w.conn_ij, w.conn_ratio, w.result_block, w.sel_count, w.sel_ij, w.sel_r,
-                    w.entries_work, w.sel_sa, w.sel_sb};
+                    w.entries_work, w.sel_sa, w.sel_sb, w.seen};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     w = PostWorkspace();
 }
@@ -381,6 +381,7 @@ static int ensure_ws_obj(lwp_context* h, PostWorkspace& w, int N, hipStream_t st
     }
     WS_ALLOC(entries_work, (size_t)N * c.max_entries * 20, double);
     WS_ALLOC(sel_count, N * 19, int);
+    WS_ALLOC(seen, N * 37, int);
     WS_ALLOC(sel_ij, (size_t)N * 19 * c.max_kpts, int);
     WS_ALLOC(sel_r, (size_t)N * 19 * c.max_kpts, double);
     WS_ALLOC(sel_sa, (size_t)N * 19 * c.max_kpts, float);
@@ -467,6 +468,7 @@ static PostWorkspace ws_frames(const PostWorkspace& w, int f0) {
     v.conn_count += f * 19; v.conn_ij += f * 19 * c.max_conn; v.conn_ratio += f * 19 * c.max_conn;
     v.flags += f * 4;
     v.sel_count += f * 19; v.sel_ij += f * 19 * c.max_kpts; v.sel_r += f * 19 * c.max_kpts;
+    v.seen += f * 37;
     v.sel_sa += f * 19 * c.max_kpts; v.sel_sb += f * 19 * c.max_kpts;
     v.entries_work += f * c.max_entries * 20; v.entries += f * c.max_entries * 20;
     v.n_entries += f; v.kpts_out += f * 18 * c.max_kpts * 4;
@@ -1400,6 +1402,19 @@ extern "C" int lwp_debug_layer_output(lwp_handle h, const float* in, int N, int 
 extern "C" int lwp_debug_frames_per_pass(lwp_handle h, int N, int H, int W) {
     if (!h || N <= 0 || H <= 0 || W <= 0) return LWP_ERR_ARG;
     return frames_per_pass(h, N, H, W);
+}
+
+extern "C" int lwp_debug_post_counts(lwp_handle h, int frame, int* peaks18, int* kpts18, int* candidates19, int* picked19) {
+    if (!h || !peaks18 || !kpts18 || !candidates19 || !picked19) return fail(h, LWP_ERR_ARG, "null argument");
+    if (frame < 0 || frame >= h->ws.N) return fail(h, LWP_ERR_ARG, "frame outside the last batch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->post_stream != h->stream) HIP_TRY(h, hipStreamSynchronize(h->post_stream));
+    HIP_TRY(h, hipMemcpy(peaks18, h->ws.seen + frame * 37, 18 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(kpts18, h->ws.kpt_count + frame * 18, 18 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(candidates19, h->ws.seen + frame * 37 + 18, 19 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(picked19, h->ws.sel_count + frame * 19, 19 * sizeof(int), hipMemcpyDeviceToHost));
+    return LWP_OK;
 }
 
 extern "C" int lwp_debug_layer_variant(lwp_handle h, int idx, char* name, int name_cap) {

@@ -219,6 +219,7 @@ struct PostWorkspace {    // device buffers, sized for (N frames, caps)
                                           //        1: min order of a pair whose mid-point test failed,
                                           //        2: min order of a pair whose mid-point test passed
     int* sel_count = nullptr;       // [N*19]  connections picked by the greedy matching
+    int* seen = nullptr;            // [N*37]  debug: peaks per type nms_kernel saw [18], candidates per limb match_kernel saw [19] (the counters themselves are re-armed by assemble_kernel)
     int* sel_ij = nullptr;          // [N*19*max_kpts]
     double* sel_r = nullptr;        // [N*19*max_kpts]
     float* sel_sa = nullptr;        // [N*19*max_kpts] score of the connection's first key-point

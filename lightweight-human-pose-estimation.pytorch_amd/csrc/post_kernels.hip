@@ -675,9 +675,53 @@ __global__ void __launch_bounds__(64) nms_kernel(int ntypes, PostWorkspace ws) {
     const int cap = ws.caps.max_peaks;
     int cnt = ws.peak_count[slot];
     const int frame = slot / ntypes;
+    if (lane == 0 && ntypes == 18) ws.seen[frame * 37 + slot % 18] = cnt;      // debug read-out (lwp_debug_post_counts)
     if (cnt > cap) {
         if (lane == 0) atomicOr(&ws.flags[frame * 4 + 0], 1ull);
         cnt = cap;
+    }
+    const int kcap0 = ws.caps.max_kpts;
+    if (cnt <= 64) {
+        // Register form for the usual case (a few dozen candidates per type): one candidate per lane, bitonic sort by key through
+        // lane exchanges, then the greedy pass as a wave-uniform loop over i — read lane i's coordinates (v_readlane), every later lane
+        // tests its distance, one ballot clears the suppressed ones.  The survivors write themselves out in parallel at the rank
+        // popcount(alive below me).  No LDS, no barrier: ~2 us instead of ~12 (the LDS form pays a barrier per compare-exchange pass
+        // and per candidate).  Same order (keys are unique: one pixel, one candidate), same survivors, same overflow flags.
+        uint32_t k = lane < cnt ? ws.peak_key[(int64_t)slot * cap + lane] : 0xFFFFFFFFu;
+        float v = lane < cnt ? ws.peak_val[(int64_t)slot * cap + lane] : 0.f;
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                const uint32_t ok = (uint32_t)__shfl_xor((int)k, j);
+                const float ov = __shfl_xor(v, j);
+                const bool lower = (lane & j) == 0, up = (lane & kk) == 0;
+                const bool take_min = lower == up;           // this lane keeps the smaller key of the pair
+                if (take_min ? ok < k : ok > k) { k = ok; v = ov; }
+            }
+        }
+        const int x = (int)(k >> 16), y = (int)(k & 0xFFFF);
+        unsigned long long alive = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        for (int i = 0; i < cnt; ++i) {
+            if (!((alive >> i) & 1ull)) continue;            // wave-uniform
+            const int xi = __builtin_amdgcn_readlane(x, i), yi = __builtin_amdgcn_readlane(y, i);
+            const int dx = x - xi, dy = y - yi;
+            const unsigned long long kill = __ballot(lane > i && lane < cnt && dx * dx + dy * dy < 36);
+            alive &= ~kill;
+        }
+        const int kept = __popcll(alive);
+        const bool mine = (alive >> lane) & 1ull;
+        const int rank = __popcll(alive & ((1ull << lane) - 1ull));
+        if (mine && rank < kcap0) {
+            ws.kpt_xy[((int64_t)slot * kcap0 + rank) * 2 + 0] = x;
+            ws.kpt_xy[((int64_t)slot * kcap0 + rank) * 2 + 1] = y;
+            ws.kpt_score[(int64_t)slot * kcap0 + rank] = v;
+        }
+        if (lane == 0) {
+            if (kept > kcap0) atomicOr(&ws.flags[frame * 4 + 0], 2ull);
+            ws.kpt_count[slot] = kept < kcap0 ? kept : kcap0;
+        }
+        return;
     }
     int n2 = 64;
     while (n2 < cnt) n2 <<= 1;
@@ -845,7 +889,22 @@ constexpr int MATCH_LDS = 1024;
 __device__ __forceinline__ bool better(double ra, int ija, double rb, int ijb) {
     return ra > rb || (ra == rb && ija < ijb);     // descending ratio, ties in (i, j) order = stable sort
 }
-__global__ void __launch_bounds__(64) match_kernel(PostWorkspace ws) {
+// 64 candidates, one per lane, into the reference's order (ratio descending, (i, j) ascending): bitonic network through lane exchanges
+__device__ __forceinline__ void sort64_candidates(double& r, int& ij, int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            const double orr = __shfl_xor(r, j);
+            const int oij = __shfl_xor(ij, j);
+            const bool lower = (lane & j) == 0, up = (lane & kk) == 0;
+            const bool want_first = lower == up;             // this lane keeps the candidate that sorts first
+            const bool other_first = better(orr, oij, r, ij);
+            if (want_first ? other_first : (!other_first && (orr != r || oij != ij))) { r = orr; ij = oij; }
+        }
+    }
+}
+__global__ void __launch_bounds__(64) match_kernel(PostWorkspace ws, int rounds_ok) {
     __shared__ double s_r[MATCH_LDS];
     __shared__ int s_ij[MATCH_LDS];
     extern __shared__ __attribute__((aligned(16))) int used[];     // [2 * kcap]
@@ -855,6 +914,7 @@ __global__ void __launch_bounds__(64) match_kernel(PostWorkspace ws) {
     const int ta = c_limb_kpt[limb][0], tb = c_limb_kpt[limb][1];
     const int na = ws.kpt_count[n * 18 + ta], nb = ws.kpt_count[n * 18 + tb];
     int m = ws.conn_count[slot];
+    if (lane == 0) ws.seen[n * 37 + 18 + limb] = m;                            // debug read-out (lwp_debug_post_counts)
     if (m > ccap) {
         if (lane == 0) atomicOr(&ws.flags[n * 4 + 0], 4ull);
         m = ccap;
@@ -877,15 +937,109 @@ __global__ void __launch_bounds__(64) match_kernel(PostWorkspace ws) {
             row[3] = (double)(below + i);
         }
     }
+    const int want = na < nb ? na : nb;
+    int nsel = 0;
+    int* sel_ij = ws.sel_ij + (int64_t)slot * kcap;
+    double* sel_r = ws.sel_r + (int64_t)slot * kcap;
+    if (m <= 64 && na <= 64 && nb <= 64) {
+        // Register form for the usual case: one candidate per lane, bitonic sort by (ratio descending, (i, j) ascending) = the
+        // reference's stable sort, then ONE wave-uniform pass over the sorted candidates with the used end points as two 64-bit
+        // masks in scalar registers (the general form below finds every pick with a full scan + a 6-step f64 reduction + a barrier:
+        // ~1 us per pick).  Same picks in the same order.
+        int ij = lane < m ? cij[lane] : 0x7FFFFFFF;
+        double r = lane < m ? crat[lane] : -1.0e300;
+        sort64_candidates(r, ij, lane);
+        unsigned long long used_a = 0ull, used_b = 0ull;
+        int my_rank = -1;                                    // pick order of this lane's candidate
+        for (int q = 0; q < m && nsel < want; ++q) {         // wave-uniform
+            const int cand = __builtin_amdgcn_readlane(ij, q);
+            const int ia = cand >> 16, jb = cand & 0xFFFF;
+            if (((used_a >> ia) & 1ull) || ((used_b >> jb) & 1ull)) continue;
+            used_a |= 1ull << ia; used_b |= 1ull << jb;
+            if (lane == q) my_rank = nsel;
+            ++nsel;
+        }
+        if (my_rank >= 0) {                                  // the picked lanes write themselves out (and gather their end points' scores) in parallel
+            sel_ij[my_rank] = ij; sel_r[my_rank] = r;
+            ws.sel_sa[(int64_t)slot * kcap + my_rank] = ws.kpt_score[(int64_t)(n * 18 + ta) * kcap + (ij >> 16)];
+            ws.sel_sb[(int64_t)slot * kcap + my_rank] = ws.kpt_score[(int64_t)(n * 18 + tb) * kcap + (ij & 0xFFFF)];
+        }
+        if (lane == 0) ws.sel_count[slot] = nsel;
+        return;
+    }
     const bool in_lds = m <= MATCH_LDS;
     if (in_lds)
         for (int q = lane; q < m; q += 64) { s_ij[q] = cij[q]; s_r[q] = crat[q]; }
     for (int i = lane; i < 2 * kcap; i += 64) used[i] = 0;
     __syncthreads();
-    const int want = na < nb ? na : nb;
-    int nsel = 0;
-    int* sel_ij = ws.sel_ij + (int64_t)slot * kcap;
-    double* sel_r = ws.sel_r + (int64_t)slot * kcap;
+    if (in_lds && want <= 64 && rounds_ok) {
+        // 65 .. 1024 candidates (a fifth of the limbs of the bench frames): rounds of DOMINANT candidates.  A candidate that is the
+        // first in the reference's order among all live candidates at BOTH of its end points is picked by the greedy pass whatever
+        // else happens (nothing ahead of it can take its end points), so every round picks all of them at once, retires the
+        // candidates that share an end point with a pick, and repeats; the globally first live candidate is always dominant, so
+        // the rounds end.  The picks of all rounds, sorted into the reference's order, are the greedy pass's picks in its pick
+        // order.  Per round: two LDS max (ratio bits: ratios are > 0, so the IEEE bits order like the values), two LDS min on
+        // (i, j) among the ties, one test — a few rounds instead of one full scan + reduction + barrier per pick.
+        unsigned long long* bestA = (unsigned long long*)(used + 2 * kcap);
+        unsigned long long* bestB = bestA + kcap;
+        int* tieA = (int*)(bestB + kcap);
+        int* tieB = tieA + kcap;
+        __shared__ int s_pick[64];
+        __shared__ int s_npick;
+        if (lane == 0) s_npick = 0;
+        unsigned alive = 0;                                      // bit t: candidate lane + 64 t
+        for (int t = 0; lane + 64 * t < m; ++t) alive |= 1u << t;
+        const int nt = (m + 63) >> 6;
+        while (__ballot(alive != 0u) != 0ull) {
+            for (int i = lane; i < kcap; i += 64) { bestA[i] = 0ull; bestB[i] = 0ull; tieA[i] = 0x7FFFFFFF; tieB[i] = 0x7FFFFFFF; }
+            __syncthreads();
+            for (int t = 0; t < nt; ++t)
+                if ((alive >> t) & 1u) {
+                    const int q = lane + 64 * t, ij = s_ij[q];
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(s_r[q]);
+                    atomicMax(&bestA[ij >> 16], key);
+                    atomicMax(&bestB[ij & 0xFFFF], key);
+                }
+            __syncthreads();
+            for (int t = 0; t < nt; ++t)
+                if ((alive >> t) & 1u) {
+                    const int q = lane + 64 * t, ij = s_ij[q];
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(s_r[q]);
+                    if (key == bestA[ij >> 16]) atomicMin(&tieA[ij >> 16], ij);
+                    if (key == bestB[ij & 0xFFFF]) atomicMin(&tieB[ij & 0xFFFF], ij);
+                }
+            __syncthreads();
+            for (int t = 0; t < nt; ++t)
+                if ((alive >> t) & 1u) {
+                    const int q = lane + 64 * t, ij = s_ij[q];
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(s_r[q]);
+                    const int ia = ij >> 16, jb = ij & 0xFFFF;
+                    if (key == bestA[ia] && key == bestB[jb] && ij == tieA[ia] && ij == tieB[jb]) {
+                        s_pick[atomicAdd(&s_npick, 1)] = q;      // <= min(na, nb) <= 64 picks in all: one per end point
+                        used[ia] = 1; used[kcap + jb] = 1;
+                    }
+                }
+            __syncthreads();
+            for (int t = 0; t < nt; ++t)
+                if ((alive >> t) & 1u) {
+                    const int ij = s_ij[lane + 64 * t];
+                    if (used[ij >> 16] || used[kcap + (ij & 0xFFFF)]) alive &= ~(1u << t);
+                }
+        }
+        __syncthreads();
+        nsel = s_npick;
+        int ij = 0x7FFFFFFF;
+        double r = -1.0e300;
+        if (lane < nsel) { const int q = s_pick[lane]; ij = s_ij[q]; r = s_r[q]; }
+        sort64_candidates(r, ij, lane);
+        if (lane < nsel) {
+            sel_ij[lane] = ij; sel_r[lane] = r;
+            ws.sel_sa[(int64_t)slot * kcap + lane] = ws.kpt_score[(int64_t)(n * 18 + ta) * kcap + (ij >> 16)];
+            ws.sel_sb[(int64_t)slot * kcap + lane] = ws.kpt_score[(int64_t)(n * 18 + tb) * kcap + (ij & 0xFFFF)];
+        }
+        if (lane == 0) ws.sel_count[slot] = nsel;
+        return;
+    }
     while (nsel < want && m > 0) {
         double br = -1.0; int bij = 0x7FFFFFFF;
         for (int q = lane; q < m; q += 64) {
@@ -917,7 +1071,9 @@ __global__ void __launch_bounds__(64) match_kernel(PostWorkspace ws) {
     if (lane == 0) ws.sel_count[slot] = nsel;
 }
 hipError_t launch_match(int N, PostWorkspace& ws, hipStream_t s) {
-    hipLaunchKernelGGL(match_kernel, dim3(19, N), dim3(64), (size_t)ws.caps.max_kpts * 2 * sizeof(int), s, ws);
+    // dynamic LDS: used [2][kcap] int (+ best [2][kcap] u64 + tie [2][kcap] int for the rounds form while that stays small)
+    const int rounds_ok = (size_t)ws.caps.max_kpts * 32 <= 32 * 1024;
+    hipLaunchKernelGGL(match_kernel, dim3(19, N), dim3(64), (size_t)ws.caps.max_kpts * (rounds_ok ? 32 : 8), s, ws, rounds_ok);
     return hipGetLastError();
 }
 

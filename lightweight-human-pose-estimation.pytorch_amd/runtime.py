@@ -337,6 +337,13 @@ class Engine(object):
             raise ValueError("bad shape")
         return n
 
+    def post_counts(self, frame=0):
+        """(peaks per type before the NMS [18], key-points per type [18], scored connection candidates per limb [19], picked
+        connections per limb [19]) of one frame of the last infer_poses / poses_from_maps call (debug)."""
+        arrs = [(C.c_int * n)() for n in (18, 18, 19, 19)]
+        check(lib().lwp_debug_post_counts(self.h.ptr, frame, *arrs), self.h.ptr)
+        return tuple(np.array(list(a), dtype=np.int64) for a in arrs)
+
     def layer_variant(self, layer_index):
         """Kernel variant the last debug_layer_output / profile_launches pass picked for a layer ("" before any)."""
         name = C.create_string_buffer(96)

@@ -353,6 +353,11 @@ def test_fused_batch_pipeline_vs_oracle_on_net_outputs():
         assert np.array_equal(e.reshape(-1, 20), np.asarray(ent, dtype=np.float64).reshape(-1, 20))
         total_k += total
     assert total_k > 100 and sum(len(r[0]) for r in res) >= 4
+    # the frames exercise BOTH forms of the matching kernel (register form up to 64 scored candidates per limb, dominant-candidate
+    # rounds beyond) and the register form of the NMS (<= 64 peaks per type); the saturated-maps test below covers the LDS forms
+    peaks, kpts, cand, picked = [np.stack(v) for v in zip(*[net.engine.post_counts(f) for f in range(2)])]
+    assert (cand > 64).any() and ((cand > 0) & (cand <= 64)).any() and peaks.max() <= 64 and peaks.max() > 0
+    assert (kpts <= peaks).all() and (picked <= np.minimum(cand, 64)).all() and picked.sum() > 0
 
 
 def test_noise_saturated_maps_with_raised_capacity():
