@@ -1609,7 +1609,8 @@ __global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
 
     const int ntiles = p.hidden / 16;
     const int my = wave < ntiles ? (ntiles - wave + NW - 1) / NW : 0;            // tiles wave, wave + NW, ...
-    f32x4 w0v[2][8], w1v[2][4], b0v[2];
+    constexpr int HPF = 3;                              // weight tiles in registers: HPF - 1 requested ahead (a tile's MFMAs take ~0.8 us, an L2 round trip 1-2)
+    f32x4 w0v[HPF][8], w1v[HPF][4], b0v[HPF];
     const __amdgpu_buffer_rsrc_t b0r = __builtin_amdgcn_make_buffer_rsrc((void*)p.b0, 0, p.hidden * 4, 0x00020000);
     const unsigned w0_lane = (unsigned)(i16 * 128 + 32 * q) * 4u, w1_lane = (unsigned)(i16 * p.hidden + 4 * q) * 4u;
     auto request = [&](int k, f32x4* a, f32x4* b, f32x4* bias) {                               // k-th tile of this wave (clamped: no branch around loads)
@@ -1622,6 +1623,7 @@ __global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
         *bias = ld(b0r, 16u * q, (unsigned)htc * 64u);                               // the tile's bias rides with its weights (exact vmcnt counting)
     };
     request(0, w0v[0], w1v[0], &b0v[0]);
+    if (HPF > 2) request(1, w0v[1], w1v[1], &b0v[1]);
     f32x4 xf[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) xf[u] = ld(xr, mok ? (unsigned)((m * p.in_ld + 32 * q + 4 * u) * 4) : 0x80000000u, 0);
@@ -1635,7 +1637,7 @@ __global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
     const int t_first_hi = p.out_split > 0 ? p.out_split / 16 : 0;          // output tiles [t_first_hi, 4) hold outputs of the second
     auto one = [&](int k, auto P_) {
         constexpr int P = decltype(P_)::value;
-        request(k + 1, w0v[P ^ 1], w1v[P ^ 1], &b0v[P ^ 1]);
+        request(k + HPF - 1, w0v[(P + HPF - 1) % HPF], w1v[(P + HPF - 1) % HPF], &b0v[(P + HPF - 1) % HPF]);
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 b0 = b0v[P];
         f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1659,11 +1661,13 @@ __global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
         }
     };
     int k = 0;
-    for (; k + 2 <= my; k += 2) {
+    for (; k + HPF <= my; k += HPF) {
         one(k, std::integral_constant<int, 0>{});
-        one(k + 1, std::integral_constant<int, 1>{});
+        one(k + 1, std::integral_constant<int, 1 % HPF>{});
+        if (HPF > 2) one(k + 2, std::integral_constant<int, 2 % HPF>{});
     }
-    if (k < my) one(k, std::integral_constant<int, 0>{});
+    if (k < my) { one(k, std::integral_constant<int, 0>{}); ++k; }
+    if (HPF > 2 && k < my) { one(k, std::integral_constant<int, 1 % HPF>{}); ++k; }
 
     // fixed-order reduction of the NW partial tiles: [wave][t][lane] f32x4
 #pragma unroll
