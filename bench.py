@@ -47,7 +47,7 @@ def layer_class(l):
 
 
 # kernel-name fragments of every family (rocprofv3 kernel_stats rows are matched with these)
-KERNEL_NAMES = {"stem": ("stem_kernel",), "fused_dw_pw": ("dwpw_kernel", "dwpw_bf16_kernel", "dwpw_bf16_pp_kernel"), "depthwise": ("dw_kernel", "dw_tiled_kernel"),
+KERNEL_NAMES = {"stem": ("stem_kernel",), "fused_dw_pw": ("dwpw_kernel", "dwpw_bf16_kernel", "dwpw_bf16_pp_kernel", "dwpw_pipe_kernel", "dwpw_tiled_kernel"), "depthwise": ("dw_kernel", "dw_tiled_kernel"),
                 "gemm_1x1": ("gemm_ar_kernel", "gemm_wp_kernel", "gemm_kernel", "gemm_bf16_kernel", "gemm_bf16_ar_kernel", "heads_f32_kernel", "heads_bf16_kernel"),
                 "dense_3x3": ("gemm_ar_kernel", "gemm_wp_kernel", "gemm_kernel", "gemm_bf16_kernel", "gemm_bf16_ar_kernel")}
 

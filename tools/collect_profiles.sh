@@ -44,6 +44,15 @@ for cfg in "b1_fp32:--batch 1 --steps 20" "b32_fp32:--batch 32 --steps 4" "b32_b
   rm -rf $ROOT/$OUT/pmc_mfma
   echo "mfma util $tag done"
 done
+# 2c. issue / LDS counters per kernel (two passes; tools/pmc_summary.py): VALU and LDS activity, bank conflicts, wait cycles
+for cfg in "b1_fp32:--batch 1 --steps 20" "b32_bf16:--batch 32 --dtype bf16 --steps 3"; do
+  tag=${cfg%%:*}; fl=${cfg#*:}
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $ROOT/$OUT/pmc_sqa -- python3 $ROOT/bench.py --streams 1 $fl --warmup 1 --preroll 0 --min-time 0.05 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS --output-format csv -d $ROOT/$OUT/pmc_sqb -- python3 $ROOT/bench.py --streams 1 $fl --warmup 1 --preroll 0 --min-time 0.05 --no-cpu-baseline --no-extra-configs > /dev/null 2>&1
+  (cd $ROOT && python3 tools/pmc_summary.py $OUT/pmc_sq_$tag.txt $OUT/pmc_sqa $OUT/pmc_sqb > /dev/null)
+  rm -rf $ROOT/$OUT/pmc_sqa $ROOT/$OUT/pmc_sqb
+  echo "sq counters $tag done"
+done
 cd $ROOT
 # 3. per-launch tables (HIP events), the depthwise / stem roofline, the bf16 agreement figures and the un-profiled bench line
 python3 tools/profile_layers.py --batch 1 > $OUT/launch_table_b1_fp32.txt 2>/dev/null
@@ -52,6 +61,11 @@ python3 tools/profile_layers.py --batch 32 --dtype bf16 > $OUT/launch_table_b32_
 for sz in "368 368 s05" "368 656 s10" "552 984 s15"; do set -- $sz; python3 tools/profile_layers.py --batch 32 --nref 3 --height $1 --width $2 --reps 5 > $OUT/launch_table_cfg4_$3.txt 2>/dev/null; done
 python3 tools/dw_roofline.py 32 > $OUT/depthwise_roofline_b32_fp32.txt 2>/dev/null
 python3 tools/bf16_agreement.py 4 > $OUT/bf16_agreement.json 2>/dev/null
+python3 tools/post_counts.py 32 fp32 > $OUT/post_counts_b32_fp32.txt 2>/dev/null
+python3 tools/post_sweep.py 32 fp32 ";" > $OUT/post_chain_b32_fp32.txt 2>/dev/null
+python3 tools/post_sweep.py 32 bf16 ";" > $OUT/post_chain_b32_bf16.txt 2>/dev/null
+python3 tools/post_sweep.py 1 fp32 ";" > $OUT/post_chain_b1_fp32.txt 2>/dev/null
+python3 tools/u8_probe.py > $OUT/u8_boundary_b1_fp32.txt 2>/dev/null
 echo "tables done"
 python3 bench.py > $OUT/bench_default.json 2>/dev/null
 # 4. multi-rank rehearsal of the N > 1 bench path on this ONE card (real engines, gloo instead of RCCL, 4 ranks: the box allows
