@@ -826,7 +826,13 @@ static int upload_host(lwp_context* h, const void* src, size_t bytes, void* dst,
         }
         if (!h->pin_ev[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->pin_ev[k], hipEventDisableTiming));
         std::memcpy(h->pin_buf[k], src, bytes);
-        HIP_TRY(h, hipMemcpyAsync(dst, h->pin_buf[k], bytes, hipMemcpyHostToDevice, h->stream));
+        if (h->tune.host_fetch_dma == 1) {                   // LWP_HOST_FETCH_DMA=1: the copy engine instead of the fetch kernel (A/B)
+            HIP_TRY(h, hipMemcpyAsync(dst, h->pin_buf[k], bytes, hipMemcpyHostToDevice, h->stream));
+        } else {
+            void* mapped = nullptr;
+            HIP_TRY(h, hipHostGetDevicePointer(&mapped, h->pin_buf[k], 0));
+            HIP_TRY(h, launch_fetch_host(mapped, dst, bytes, h->stream));
+        }
         HIP_TRY(h, hipEventRecord(h->pin_ev[k], h->stream));
         h->pin_busy[k] = true;
         *consumed = true;

@@ -105,6 +105,7 @@ struct Tuning {
     int max_frames_per_pass = 0;                                   // LWP_MAX_FRAMES_PER_PASS (tests: split batches as if the 2 GiB limit were reached earlier)
     int peak_tile = -1, pair_form = -1;                            // LWP_PEAK_TILE (find_peaks tile 0..3), LWP_PAIR_FORM (score_pairs variant)
     int dwpw_lds_pad_kb = 0;                                       // LWP_DWPW_LDS_PAD (KB of unused LDS per workgroup of the bf16 fused blocks: occupancy experiments)
+    int host_fetch_dma = -1;                                       // LWP_HOST_FETCH_DMA ("1": host frames by hipMemcpyAsync instead of the fetch kernel)
     int post_nchw = -1;                                            // LWP_POST_NCHW (f32: "0" = grouping reads the NHWC concat buffer in place)
     int heads_f32_max_m = 0;                                       // LWP_HEADS_F32_MAXM (tests: force the fused fp32 head pair at larger M)
 };
@@ -265,6 +266,7 @@ struct PreScaleParams {
 };
 void build_resize_table_ratio(int n_src, int n_dst, double ratio, std::vector<int>& idx, std::vector<float>& w);
 hipError_t launch_preprocess_scaled(const PreScaleParams& p, hipStream_t s);
+hipError_t launch_fetch_host(const void* src_host_mapped, void* dst, size_t bytes, hipStream_t s);
 hipError_t launch_publish(int N, PostWorkspace& ws, void* host_block, hipStream_t s);   // used rows -> pinned host block
 void build_resize_table(int n_src, int n_dst, std::vector<int>& idx, std::vector<float>& w);
 hipError_t launch_resize_accum(const float* src, int N, int Hs, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,

@@ -454,6 +454,27 @@ hipError_t launch_publish(int N, PostWorkspace& ws, void* host_block, hipStream_
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ host frames
+// Pinned (device-mapped) host memory -> device buffer, as a KERNEL: 16-byte loads, every byte crosses PCIe once.  A hipMemcpyAsync
+// may be routed through an SDMA queue, which stalls for milliseconds when it has to wake up (see publish_results_kernel) — with
+// three engine streams feeding frames the DMA form ran 1800-2200 frames/s from run to run.
+__global__ void __launch_bounds__(256) fetch_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
+                                                        const unsigned char* src_tail, unsigned char* dst_tail, int ntail) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t k = i; k < n16; k += stride) dst[k] = src[k];
+    if (i < (size_t)ntail) dst_tail[i] = src_tail[i];
+}
+hipError_t launch_fetch_host(const void* src_host_mapped, void* dst, size_t bytes, hipStream_t s) {
+    const size_t n16 = bytes / 16;
+    const int ntail = (int)(bytes - n16 * 16);
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(fetch_host_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)src_host_mapped, (uint4*)dst, n16,
+                       (const unsigned char*)src_host_mapped + n16 * 16, (unsigned char*)dst + n16 * 16, ntail);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ peaks
 // keypoints.py:17-30: threshold, zero border, strict > against the 4 neighbours.
 // One PTH x PTW tile of full-res pixels per workgroup.  For R = 4 / 8 the up-sampled values (tile + halo 1) are

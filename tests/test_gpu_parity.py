@@ -604,6 +604,35 @@ def test_preprocess_u8_non_default_mean_scale_pad(eng):
     assert pad[1] > 0 and want[0, 1, 0, 0] == np.float32(7.5)
 
 
+def test_host_frames_are_free_on_return_and_staging_buffers_rotate():
+    """Host frames travel through two pinned staging buffers (memcpy on the calling thread, asynchronous DMA): the call returns
+    without waiting for the copy, so (a) the caller may overwrite its frame buffer right after the call — the result must be that of
+    the ORIGINAL content; (b) a staging buffer is reused (third call) only after the DMA that read it; (c) a larger frame grows the
+    buffer it lands in.  Two frame sizes alternate over seven calls issued back to back, every output is checked afterwards; the
+    float32 multi-scale entry takes the same route."""
+    from oracle import preproc_ref
+    eng2 = Engine(0)
+    shapes = [(240, 200), (368, 656), (240, 200), (300, 500), (368, 656), (120, 90), (368, 656)]
+    frames = [synth.make_frames(1, h, w, seed0=40 + i)[0] for i, (h, w) in enumerate(shapes)]
+    wants = [preproc_ref.prepare_frame(f, 368, 8)[0] for f in frames]
+    outs = []
+    for f in frames:
+        buf = f.copy()
+        x, _, _ = eng2.preprocess_u8(buf, 368, 8)
+        buf[...] = 255 - buf                                # the caller reuses its buffer at once
+        outs.append(x)
+    torch.cuda.synchronize()
+    for x, w in zip(outs, wants):
+        assert np.array_equal(x.cpu().numpy(), w)
+    imgs = np.stack([synth.make_frames(1, 96, 128, seed0=60 + i)[0] for i in range(3)]).astype(np.float32)
+    buf = imgs.copy()
+    x, pad2 = eng2.preprocess_scaled_u8(buf, 1.5, 368, 8)
+    buf[...] = 0.0
+    y, pad3 = eng2.preprocess_scaled_u8(imgs.astype(np.uint8), 1.5, 368, 8)       # the uint8 twin of the same frames (pinned against the oracle above)
+    torch.cuda.synchronize()
+    assert pad2 == pad3 and np.array_equal(x.cpu().numpy(), y.cpu().numpy())
+
+
 def test_infer_fast_from_u8_frame_matches_oracle_pipeline():
     """demo.infer_fast end to end from a uint8 frame that needs resizing: maps within the network tolerance of the
     oracle (oracle pre-processing -> oracle forward -> oracle x4 cubic up-sampling), same scale and pad."""
