@@ -36,7 +36,7 @@ struct lwp_context {
     std::vector<size_t> d_outs_bytes;
     float* d_tmp = nullptr; size_t d_tmp_bytes = 0;     // generic device staging (upsample / extract / group)
     float* d_tmp2 = nullptr; size_t d_tmp2_bytes = 0;
-    struct ResizeTab { int cw, ch, dw, dh; void* d; double ratio; };   // cubic resize tables of the multi-scale path, kept on the device
+    struct ResizeTab { int cw, ch, dw, dh; void* d; double ratio; int uh_max = 0, uw_max = 0; };   // cubic resize tables of the multi-scale path, kept on the device (+ the fused kernel's tile extents)
     std::vector<ResizeTab> resize_tabs;                  // (a per-call upload went through SDMA queues: multi-ms stalls on some boxes)
     std::vector<ResizeTab> scale_tabs;                   // image-side tables of lwp_preprocess_scaled_u8: (W, H, dw, dh, ratio)
     unsigned char* d_imgs = nullptr; size_t d_imgs_bytes = 0;   // uint8 frame batch staging (host frames of the multi-scale path)
@@ -735,8 +735,6 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
         HIP_TRY(h, hipMemcpyAsync(h->d_tmp, maps, sb, hipMemcpyHostToDevice, h->stream));
         d_src = h->d_tmp;
     }
-    rc = ensure_dev(h, &h->d_tmp2, &h->d_tmp2_bytes, ub);
-    if (rc) return rc;
     float* d_acc = accum;
     if (accum_mem == LWP_MEM_HOST) {
         rc = ensure_dev(h, &h->d_maps[0], &h->d_maps_bytes[0], ab);
@@ -747,13 +745,16 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     // per-geometry tables, uploaded once (blocking copy) and kept: steady-state calls issue no host->device copy
     const size_t nx = (size_t)dst_w * 4, ny = (size_t)dst_h * 4;
     void* d_tabs = nullptr;
+    int uh_max = 0, uw_max = 0;
     for (const auto& rt : h->resize_tabs)
-        if (rt.cw == cw && rt.ch == ch && rt.dw == dst_w && rt.dh == dst_h) { d_tabs = rt.d; break; }
+        if (rt.cw == cw && rt.ch == ch && rt.dw == dst_w && rt.dh == dst_h) { d_tabs = rt.d; uh_max = rt.uh_max; uw_max = rt.uw_max; break; }
     if (!d_tabs) {
         std::vector<int> xi, yi;
         std::vector<float> xw, yw;
         build_resize_table(cw, dst_w, xi, xw);
         build_resize_table(ch, dst_h, yi, yw);
+        int lh_unused = 0, lw_unused = 0;
+        multiscale_fused_extent(xi.data(), yi.data(), dst_h, dst_w, up_ratio, &uh_max, &uw_max, &lh_unused, &lw_unused);
         if (h->resize_tabs.size() >= 16) {               // bounded: drop the oldest geometry
             HIP_TRY(h, hipStreamSynchronize(h->stream));
             (void)hipFree(h->resize_tabs.front().d);
@@ -765,7 +766,7 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
         HIP_TRY(h, hipMemcpy(t0 + nx * 4, xw.data(), nx * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(t0 + nx * 8, yi.data(), ny * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(t0 + nx * 8 + ny * 4, yw.data(), ny * 4, hipMemcpyHostToDevice));
-        h->resize_tabs.push_back({cw, ch, dst_w, dst_h, d_tabs, 0.0});
+        h->resize_tabs.push_back({cw, ch, dst_w, dst_h, d_tabs, 0.0, uh_max, uw_max});
     }
     char* t = (char*)d_tabs;
     int* d_xi = (int*)t; t += nx * 4;
@@ -773,8 +774,17 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     int* d_yi = (int*)t; t += ny * 4;
     float* d_yw = (float*)t;
     MapView v{d_src, (int64_t)C * hs * ws, (int64_t)ws, 1, (int64_t)hs * ws, hs, ws};
-    LAUNCH(h, KC_POST, launch_upsample(v, N, C, up_ratio, h->d_tmp2, h->stream, &h->tune));
-    LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, N, Hs, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, init ? 1 : 0, d_acc, h->stream));
+    bool fused = false;
+    if (h->tune.ms_fused != 0) {                             // LWP_MS_FUSED=0: the two-kernel form (A/B, tests)
+        LAUNCH(h, KC_POST, launch_multiscale_fused(v, N, C, up_ratio, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, init ? 1 : 0,
+                                                   d_acc, uh_max, uw_max, (uh_max - 1) / up_ratio + 6, (uw_max - 1) / up_ratio + 6, h->stream, &fused));
+    }
+    if (!fused) {
+        rc = ensure_dev(h, &h->d_tmp2, &h->d_tmp2_bytes, ub);
+        if (rc) return rc;
+        LAUNCH(h, KC_POST, launch_upsample(v, N, C, up_ratio, h->d_tmp2, h->stream, &h->tune));
+        LAUNCH(h, KC_POST, launch_resize_accum(h->d_tmp2, N, Hs, Ws, C, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, init ? 1 : 0, d_acc, h->stream));
+    }
     if (accum_mem == LWP_MEM_HOST) HIP_TRY(h, hipMemcpyAsync(accum, d_acc, ab, hipMemcpyDeviceToHost, h->stream));
     bool ordered = false;
     if (accum_mem == LWP_MEM_DEVICE) { rc = order_out(h, h->stream, &ordered); if (rc) return rc; }

@@ -266,6 +266,203 @@ hipError_t launch_resize_accum(const float* src, int N, int Hs, int Ws, int C, i
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ fused multi-scale step
+// val.py:96-108 for one scale WITHOUT the x8 map in memory: up-sample (cv2 cubic, x R) + crop + cubic resize to the frame size +
+// avg += m / n in ONE kernel.  The two-kernel form writes the up-sampled map (2.6 GB for 32 x 552 x 984 x 38 floats) and gathers
+// it back 16 taps per output element: 15.6 % of the config-4 step at 1.3-2.9 TB/s.  Here a workgroup owns MS_TY x MS_TX output
+// pixels x CG channels and walks the four separable passes through LDS:
+//   lo  [LH][LW][CG]   the low-resolution patch (replicate border), read once
+//   hz  [LH][UW][CG]   up-sampling, horizontal pass  (sample_map's products and left-to-right sums)
+//   up  [UH][UW][CG]   up-sampling, vertical pass    = the x R map on the rows / columns this tile's taps touch
+//   h2  [UH][TX][CG]   resize, horizontal pass       (resize_accum_kernel's products and sums; aliases lo / hz)
+//   out                resize, vertical pass + accumulate, channel-fastest stores
+// The value of a (row, column) pair of every pass does not depend on which output pixel asks for it, so the bits are those of the
+// two-kernel form (tested against it and against the oracle).  HBM traffic: the accumulator's read + write.
+constexpr int MS_TY = 8, MS_TX = 16;
+template <int R, int CG>
+__global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int C, int crop_top, int crop_left, const int* __restrict__ xi,
+                                                               const float* __restrict__ xw, const int* __restrict__ yi, const float* __restrict__ yw,
+                                                               int dst_h, int dst_w, float divisor, int init, float* __restrict__ accum,
+                                                               int lo_hz_floats) {
+    extern __shared__ float msm[];
+    const CubicTable& ct = g_cubic[R == 4 ? 0 : 1];
+    const int tiles_x = (dst_w + MS_TX - 1) / MS_TX;
+    const int x0 = (blockIdx.x % tiles_x) * MS_TX, y0 = (blockIdx.x / tiles_x) * MS_TY;
+    const int x1 = min(x0 + MS_TX, dst_w), y1 = min(y0 + MS_TY, dst_h);
+    const int c0 = blockIdx.y * CG, n = blockIdx.z;
+    const int tid = threadIdx.x;
+    // rows / columns of the x R map this tile's taps touch (the tables hold clamped, non-decreasing indices into the crop)
+    const int ua = crop_top + yi[y0 * 4], ub = crop_top + yi[(y1 - 1) * 4 + 3];
+    const int va = crop_left + xi[x0 * 4], vb = crop_left + xi[(x1 - 1) * 4 + 3];
+    const int UH = ub - ua + 1, UW = vb - va + 1;
+    const int la = ua / R - 2, ka = va / R - 2;                        // first low-resolution row / column (taps q + off - 1 .. + 2, off in {-1, 0})
+    const int LH = ub / R + 2 - la + 1, LW = vb / R + 2 - ka + 1;
+    float* lo = msm;                                                   // [LH][LW][CG]
+    float* hz = lo + LH * LW * CG;                                     // [LH][UW][CG]
+    float* up = msm + lo_hz_floats;                                    // [UH][UW][CG]
+    float* h2 = msm;                                                   // [UH][x1 - x0][CG]  (lo / hz are dead by then)
+    const float* base = src.base + (int64_t)n * src.ns + (int64_t)c0 * src.cs;
+    // the accumulator values this thread will update are requested NOW: their latency hides behind the four passes (at the
+    // magnifying scales a workgroup's passes are short and the read-modify-write at the end was an exposed round trip)
+    constexpr int K2 = 2;                                              // items per thread and output row: TX * CG <= 512 (host-checked)
+    const int W2 = (x1 - x0) * CG;
+    int xl2[K2], c2[K2];
+    float accv[MS_TY][K2];
+#pragma unroll
+    for (int k = 0; k < K2; ++k) {
+        const int i = tid + 256 * k, ic = i < W2 ? i : 0;
+        xl2[k] = ic / CG; c2[k] = ic - xl2[k] * CG;
+    }
+#pragma unroll
+    for (int r = 0; r < MS_TY; ++r)
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            const int y = y0 + r;
+            accv[r][k] = (!init && y < y1 && tid + 256 * k < W2) ? accum[(((int64_t)n * dst_h + y) * dst_w + x0 + xl2[k]) * C + c0 + c2[k]] : 0.f;
+        }
+    if (tid < LH * LW) {                                               // lanes along x: contiguous runs of the channel planes
+        const int j = tid / LW, k = tid - j * LW;
+        const float* p = base + (int64_t)clampi(la + j, 0, src.h - 1) * src.ys + (int64_t)clampi(ka + k, 0, src.w - 1) * src.xs;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) lo[tid * CG + c] = p[(int64_t)c * src.cs];
+    }
+    __syncthreads();
+    // A thread's items of a row — (column, channel) pairs tid, tid + 256, ... — are the same for every row of a pass, so their tap
+    // offsets and weights are computed ONCE per pass (the first version redid the index arithmetic and the table loads per row and
+    // item: ~300 instructions per output element; ~170 now, most of them the up-sampled values of the tile's halo).
+    constexpr int K1 = 3;                                              // items per thread and row: UW * CG <= 768 (host-checked)
+    const int W1 = UW * CG;
+    {                                                                  // up-sampling, horizontal
+        int off[K1];
+        float w[K1][4];
+#pragma unroll
+        for (int k = 0; k < K1; ++k) {
+            const int i = tid + 256 * k, ic = i < W1 ? i : 0;
+            const int u = ic / CG, c = ic - u * CG;
+            const int X = va + u, qx = X / R, px = X - qx * R;
+            off[k] = (qx + ct.off[px] - 1 - ka) * CG + c;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[k][t] = ct.w[px][t];
+        }
+        for (int j = 0; j < LH; ++j) {
+            const float* lrow = lo + j * LW * CG;
+#pragma unroll
+            for (int k = 0; k < K1; ++k) {
+                const int i = tid + 256 * k;
+                if (i < W1) {
+                    const float* row = lrow + off[k];
+                    float a = __fmul_rn(row[0], w[k][0]);
+                    a = __fadd_rn(a, __fmul_rn(row[CG], w[k][1]));
+                    a = __fadd_rn(a, __fmul_rn(row[2 * CG], w[k][2]));
+                    a = __fadd_rn(a, __fmul_rn(row[3 * CG], w[k][3]));
+                    hz[j * W1 + i] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int v = 0; v < UH; ++v) {                                     // up-sampling, vertical (row and weights are wave-uniform)
+        const int Y = ua + v, qy = Y / R, py = Y - qy * R;
+        const float* rows = hz + (qy + ct.off[py] - 1 - la) * W1;
+        const float w0 = ct.w[py][0], w1 = ct.w[py][1], w2 = ct.w[py][2], w3 = ct.w[py][3];
+#pragma unroll
+        for (int k = 0; k < K1; ++k) {
+            const int i = tid + 256 * k;
+            if (i < W1) {
+                float t = __fmul_rn(rows[i], w0);
+                t = __fadd_rn(t, __fmul_rn(rows[W1 + i], w1));
+                t = __fadd_rn(t, __fmul_rn(rows[2 * W1 + i], w2));
+                t = __fadd_rn(t, __fmul_rn(rows[3 * W1 + i], w3));
+                up[v * W1 + i] = t;
+            }
+        }
+    }
+    __syncthreads();
+    {                                                                  // resize, horizontal
+        int off[K2][4];
+        float w[K2][4];
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                off[k][t] = (crop_left + xi[(x0 + xl2[k]) * 4 + t] - va) * CG + c2[k];
+                w[k][t] = xw[(x0 + xl2[k]) * 4 + t];
+            }
+        }
+        for (int v = 0; v < UH; ++v) {
+            const float* row = up + v * W1;
+#pragma unroll
+            for (int k = 0; k < K2; ++k) {
+                const int i = tid + 256 * k;
+                if (i < W2) {
+                    float a = __fmul_rn(row[off[k][0]], w[k][0]);
+                    a = __fadd_rn(a, __fmul_rn(row[off[k][1]], w[k][1]));
+                    a = __fadd_rn(a, __fmul_rn(row[off[k][2]], w[k][2]));
+                    a = __fadd_rn(a, __fmul_rn(row[off[k][3]], w[k][3]));
+                    h2[v * W2 + i] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MS_TY; ++r) {                                  // resize, vertical + accumulate (rows and weights are wave-uniform)
+        const int y = y0 + r;
+        if (y >= y1) break;
+        const int r0 = (crop_top + yi[y * 4] - ua) * W2, r1 = (crop_top + yi[y * 4 + 1] - ua) * W2, r2 = (crop_top + yi[y * 4 + 2] - ua) * W2, r3 = (crop_top + yi[y * 4 + 3] - ua) * W2;
+        const float w0 = yw[y * 4], w1 = yw[y * 4 + 1], w2 = yw[y * 4 + 2], w3 = yw[y * 4 + 3];
+        float* drow = accum + (((int64_t)n * dst_h + y) * dst_w + x0) * C + c0;
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            const int i = tid + 256 * k;
+            if (i < W2) {
+                float o = __fmul_rn(h2[r0 + i], w0);
+                o = __fadd_rn(o, __fmul_rn(h2[r1 + i], w1));
+                o = __fadd_rn(o, __fmul_rn(h2[r2 + i], w2));
+                o = __fadd_rn(o, __fmul_rn(h2[r3 + i], w3));
+                float* dst = drow + xl2[k] * C + c2[k];
+                *dst = __fadd_rn(accv[r][k], __fdiv_rn(o, divisor));       // first scale: 0 + m / n (val.py:86-87), the same bits
+            }
+        }
+    }
+}
+// host: LDS floats of the largest tile of a geometry (called once per geometry; the tables are the host copies)
+void multiscale_fused_extent(const int* xi, const int* yi, int dst_h, int dst_w, int R, int* uh_max, int* uw_max, int* lh_max, int* lw_max) {
+    *uh_max = *uw_max = *lh_max = *lw_max = 0;
+    for (int y0 = 0; y0 < dst_h; y0 += MS_TY) {
+        const int y1 = std::min(y0 + MS_TY, dst_h), a = yi[y0 * 4], b = yi[(y1 - 1) * 4 + 3];
+        *uh_max = std::max(*uh_max, b - a + 1);
+    }
+    for (int x0 = 0; x0 < dst_w; x0 += MS_TX) {
+        const int x1 = std::min(x0 + MS_TX, dst_w), a = xi[x0 * 4], b = xi[(x1 - 1) * 4 + 3];
+        *uw_max = std::max(*uw_max, b - a + 1);
+    }
+    // low-resolution extent of a run of U rows starting anywhere: at most (U - 1) / R + 1 distinct q, + 1 for the phase, + 4 taps
+    *lh_max = (*uh_max - 1) / R + 6;
+    *lw_max = (*uw_max - 1) / R + 6;
+}
+// *used = false: the geometry does not fit the LDS (or the channel count is no multiple of 19): the caller takes the two-kernel form
+hipError_t launch_multiscale_fused(const MapView& src, int N, int C, int ratio, int crop_top, int crop_left, const int* xi, const float* xw,
+                                   const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum,
+                                   int uh_max, int uw_max, int lh_max, int lw_max, hipStream_t s, bool* used) {
+    *used = false;
+    constexpr int CG = 19;
+    if ((ratio != 4 && ratio != 8) || C % CG != 0 || uh_max <= 0 || uw_max <= 0) return hipSuccess;
+    if (lh_max * lw_max > 256) return hipSuccess;                       // one thread per low-resolution pixel of the patch
+    if (uw_max * CG > 768 || MS_TX * CG > 512) return hipSuccess;       // items per thread and row (K1, K2 in the kernel)
+    const size_t lo_hz = (size_t)(lh_max * lw_max + lh_max * uw_max) * CG, h2 = (size_t)uh_max * MS_TX * CG;
+    const size_t a = lo_hz > h2 ? lo_hz : h2, lds = (a + (size_t)uh_max * uw_max * CG) * sizeof(float);
+    if (lds > 96 * 1024) return hipSuccess;
+    static LdsAttrOnce attr4, attr8;
+    hipError_t e = ratio == 4 ? attr4.ensure((const void*)multiscale_fused_kernel<4, CG>, 96 * 1024) : attr8.ensure((const void*)multiscale_fused_kernel<8, CG>, 96 * 1024);
+    if (e != hipSuccess) return e;
+    *used = true;
+    const dim3 grid(((dst_w + MS_TX - 1) / MS_TX) * ((dst_h + MS_TY - 1) / MS_TY), C / CG, N);
+    if (ratio == 4) hipLaunchKernelGGL((multiscale_fused_kernel<4, CG>), grid, dim3(256), lds, s, src, C, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
+    else hipLaunchKernelGGL((multiscale_fused_kernel<8, CG>), grid, dim3(256), lds, s, src, C, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) threshold_kernel(float* m, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && m[i] < 0.1f) m[i] = 0.f;     // keypoints.py:17 (NaN stays NaN)

@@ -537,6 +537,34 @@ def test_multiscale_accumulate_bit_exact(eng):
         assert np.array_equal(acc_t.cpu().numpy(), ref)
 
 
+def test_multiscale_fused_kernel_equals_the_two_kernel_form_and_the_oracle(monkeypatch):
+    """multiscale_fused_kernel (x8 / x4 up-sample + crop + cubic resize + avg += m / n through LDS, no up-sampled map in memory)
+    against the two-kernel form (LWP_MS_FUSED=0) BIT FOR BIT on 19- and 38-channel maps, batches of two, magnifying and minifying
+    resizes (ratios 0.5 / 1 / 1.5 / 2 of the reference's scale list), crops on every side, output sizes that are no multiple of the
+    8 x 16 tile, first scale (init) and later scales; one geometry also against the oracle.  17-channel maps take the two-kernel
+    form in both engines (no multiple of the channel group)."""
+    monkeypatch.setenv("LWP_MS_FUSED", "0")
+    e_two = Engine(0)
+    monkeypatch.delenv("LWP_MS_FUSED")
+    e_fus = Engine(0)
+    rng = np.random.RandomState(5)
+    cases = [  # (C, h, w, ratio, pad, dst_h, dst_w)
+        (19, 23, 46, 8, [0, 3, 0, 3], 150, 301), (38, 23, 46, 8, [20, 30, 12, 18], 184, 328), (38, 46, 46, 8, [92, 20, 92, 20], 368, 656),
+        (19, 46, 82, 8, [0, 0, 0, 0], 368, 656), (38, 69, 123, 8, [0, 0, 0, 0], 368, 656), (19, 92, 164, 8, [0, 0, 0, 0], 368, 656),
+        (38, 12, 20, 4, [1, 2, 3, 0], 37, 61), (17, 23, 46, 8, [0, 3, 0, 3], 150, 301)]
+    for C_, h, w, ratio, pad, dh, dw in cases:
+        maps = (rng.rand(2, C_, h, w).astype(np.float32) - 0.3)
+        for init in (True, False):
+            acc0 = (rng.rand(2, dh, dw, C_).astype(np.float32) - 0.5)
+            a = e_two.multiscale_accumulate(acc0.copy(), maps, ratio, pad, 3, init=init)
+            b = e_fus.multiscale_accumulate(acc0.copy(), maps, ratio, pad, 3, init=init)
+            assert np.array_equal(a, b), (C_, h, w, ratio, pad, dh, dw, init)
+    heat, _, _ = synth.make_pose_maps(3, 23, 46, 21)
+    acc0 = (synth.uniform((150, 301, 19), 78) - 0.5).astype(np.float32)
+    ref = post_ref.multiscale_accumulate(acc0.copy(), heat, 8, [0, 3, 0, 3], 301, 150, 3)
+    assert np.array_equal(e_fus.multiscale_accumulate(acc0.copy(), heat[None], 8, [0, 3, 0, 3], 3), ref)
+
+
 def test_val_infer_multiscale_matches_oracle():
     """Drop-in val.infer (scales 0.5/1.0/1.5, base height 368 -> here a reduced 184-high frame) vs the oracle driver."""
     from lwpose_amd.val import infer
