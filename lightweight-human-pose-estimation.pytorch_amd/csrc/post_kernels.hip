@@ -278,8 +278,8 @@ hipError_t launch_resize_accum(const float* src, int N, int Hs, int Ws, int C, i
 //   out                resize, vertical pass + accumulate, channel-fastest stores
 // The value of a (row, column) pair of every pass does not depend on which output pixel asks for it, so the bits are those of the
 // two-kernel form (tested against it and against the oracle).  HBM traffic: the accumulator's read + write.
-constexpr int MS_TY = 8, MS_TX = 16;
-template <int R, int CG>
+constexpr int MS_TY = 8;
+template <int R, int CG, int MS_TX>      // MS_TX = 16 | 32 output columns per workgroup (32 while the tile's x R columns still fit three items per thread)
 __global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int C, int crop_top, int crop_left, const int* __restrict__ xi,
                                                                const float* __restrict__ xw, const int* __restrict__ yi, const float* __restrict__ yw,
                                                                int dst_h, int dst_w, float divisor, int init, float* __restrict__ accum,
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int 
     const float* base = src.base + (int64_t)n * src.ns + (int64_t)c0 * src.cs;
     // the accumulator values this thread will update are requested NOW: their latency hides behind the four passes (at the
     // magnifying scales a workgroup's passes are short and the read-modify-write at the end was an exposed round trip)
-    constexpr int K2 = 2;                                              // items per thread and output row: TX * CG <= 512 (host-checked)
+    constexpr int K2 = (MS_TX * CG + 255) / 256;                       // items per thread and output row
     const int W2 = (x1 - x0) * CG;
     int xl2[K2], c2[K2];
     float accv[MS_TY][K2];
@@ -313,6 +313,15 @@ __global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int 
         const int i = tid + 256 * k, ic = i < W2 ? i : 0;
         xl2[k] = ic / CG; c2[k] = ic - xl2[k] * CG;
     }
+    int off2[K2][4];                                                   // taps of the resize's horizontal pass: requested now, used after three passes
+    float w2t[K2][4];
+#pragma unroll
+    for (int k = 0; k < K2; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            off2[k][t] = xi[(x0 + xl2[k]) * 4 + t];
+            w2t[k][t] = xw[(x0 + xl2[k]) * 4 + t];
+        }
 #pragma unroll
     for (int r = 0; r < MS_TY; ++r)
 #pragma unroll
@@ -379,26 +388,20 @@ __global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int 
     }
     __syncthreads();
     {                                                                  // resize, horizontal
-        int off[K2][4];
-        float w[K2][4];
 #pragma unroll
-        for (int k = 0; k < K2; ++k) {
+        for (int k = 0; k < K2; ++k)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                off[k][t] = (crop_left + xi[(x0 + xl2[k]) * 4 + t] - va) * CG + c2[k];
-                w[k][t] = xw[(x0 + xl2[k]) * 4 + t];
-            }
-        }
+            for (int t = 0; t < 4; ++t) off2[k][t] = (crop_left + off2[k][t] - va) * CG + c2[k];
         for (int v = 0; v < UH; ++v) {
             const float* row = up + v * W1;
 #pragma unroll
             for (int k = 0; k < K2; ++k) {
                 const int i = tid + 256 * k;
                 if (i < W2) {
-                    float a = __fmul_rn(row[off[k][0]], w[k][0]);
-                    a = __fadd_rn(a, __fmul_rn(row[off[k][1]], w[k][1]));
-                    a = __fadd_rn(a, __fmul_rn(row[off[k][2]], w[k][2]));
-                    a = __fadd_rn(a, __fmul_rn(row[off[k][3]], w[k][3]));
+                    float a = __fmul_rn(row[off2[k][0]], w2t[k][0]);
+                    a = __fadd_rn(a, __fmul_rn(row[off2[k][1]], w2t[k][1]));
+                    a = __fadd_rn(a, __fmul_rn(row[off2[k][2]], w2t[k][2]));
+                    a = __fadd_rn(a, __fmul_rn(row[off2[k][3]], w2t[k][3]));
                     h2[v * W2 + i] = a;
                 }
             }
@@ -426,41 +429,56 @@ __global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int 
         }
     }
 }
-// host: LDS floats of the largest tile of a geometry (called once per geometry; the tables are the host copies)
-void multiscale_fused_extent(const int* xi, const int* yi, int dst_h, int dst_w, int R, int* uh_max, int* uw_max, int* lh_max, int* lw_max) {
-    *uh_max = *uw_max = *lh_max = *lw_max = 0;
+// host: x R rows / columns the largest tile of a geometry touches, for tiles of MS_TY x tx output pixels (called once per geometry)
+void multiscale_fused_extent(const int* xi, const int* yi, int dst_h, int dst_w, int tx, int* uh_max, int* uw_max) {
+    *uh_max = *uw_max = 0;
     for (int y0 = 0; y0 < dst_h; y0 += MS_TY) {
         const int y1 = std::min(y0 + MS_TY, dst_h), a = yi[y0 * 4], b = yi[(y1 - 1) * 4 + 3];
         *uh_max = std::max(*uh_max, b - a + 1);
     }
-    for (int x0 = 0; x0 < dst_w; x0 += MS_TX) {
-        const int x1 = std::min(x0 + MS_TX, dst_w), a = xi[x0 * 4], b = xi[(x1 - 1) * 4 + 3];
+    for (int x0 = 0; x0 < dst_w; x0 += tx) {
+        const int x1 = std::min(x0 + tx, dst_w), a = xi[x0 * 4], b = xi[(x1 - 1) * 4 + 3];
         *uw_max = std::max(*uw_max, b - a + 1);
     }
-    // low-resolution extent of a run of U rows starting anywhere: at most (U - 1) / R + 1 distinct q, + 1 for the phase, + 4 taps
-    *lh_max = (*uh_max - 1) / R + 6;
-    *lw_max = (*uw_max - 1) / R + 6;
 }
-// *used = false: the geometry does not fit the LDS (or the channel count is no multiple of 19): the caller takes the two-kernel form
-hipError_t launch_multiscale_fused(const MapView& src, int N, int C, int ratio, int crop_top, int crop_left, const int* xi, const float* xw,
-                                   const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum,
-                                   int uh_max, int uw_max, int lh_max, int lw_max, hipStream_t s, bool* used) {
-    *used = false;
-    constexpr int CG = 19;
-    if ((ratio != 4 && ratio != 8) || C % CG != 0 || uh_max <= 0 || uw_max <= 0) return hipSuccess;
-    if (lh_max * lw_max > 256) return hipSuccess;                       // one thread per low-resolution pixel of the patch
-    if (uw_max * CG > 768 || MS_TX * CG > 512) return hipSuccess;       // items per thread and row (K1, K2 in the kernel)
-    const size_t lo_hz = (size_t)(lh_max * lw_max + lh_max * uw_max) * CG, h2 = (size_t)uh_max * MS_TX * CG;
+template <int R, int CG, int TX>
+static hipError_t launch_multiscale_fused_t(const MapView& src, int N, int C, int crop_top, int crop_left, const int* xi, const float* xw,
+                                            const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum,
+                                            int uh_max, int uw_max, hipStream_t s, bool* used) {
+    // low-resolution extent of a run of U rows starting anywhere: at most (U - 1) / R + 1 distinct q, + 1 for the phase, + 4 taps
+    const int lh_max = (uh_max - 1) / R + 6, lw_max = (uw_max - 1) / R + 6;
+    if (lh_max * lw_max > 256 || uw_max * CG > 768) return hipSuccess;   // one thread per low-resolution pixel; three items per thread and x R row
+    const size_t lo_hz = (size_t)(lh_max * lw_max + lh_max * uw_max) * CG, h2 = (size_t)uh_max * TX * CG;
     const size_t a = lo_hz > h2 ? lo_hz : h2, lds = (a + (size_t)uh_max * uw_max * CG) * sizeof(float);
     if (lds > 96 * 1024) return hipSuccess;
-    static LdsAttrOnce attr4, attr8;
-    hipError_t e = ratio == 4 ? attr4.ensure((const void*)multiscale_fused_kernel<4, CG>, 96 * 1024) : attr8.ensure((const void*)multiscale_fused_kernel<8, CG>, 96 * 1024);
+    static LdsAttrOnce attr;
+    hipError_t e = attr.ensure((const void*)multiscale_fused_kernel<R, CG, TX>, 96 * 1024);
     if (e != hipSuccess) return e;
     *used = true;
-    const dim3 grid(((dst_w + MS_TX - 1) / MS_TX) * ((dst_h + MS_TY - 1) / MS_TY), C / CG, N);
-    if (ratio == 4) hipLaunchKernelGGL((multiscale_fused_kernel<4, CG>), grid, dim3(256), lds, s, src, C, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
-    else hipLaunchKernelGGL((multiscale_fused_kernel<8, CG>), grid, dim3(256), lds, s, src, C, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
+    const dim3 grid(((dst_w + TX - 1) / TX) * ((dst_h + MS_TY - 1) / MS_TY), C / CG, N);
+    hipLaunchKernelGGL((multiscale_fused_kernel<R, CG, TX>), grid, dim3(256), lds, s, src, C, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
     return hipGetLastError();
+}
+// *used = false: the geometry does not fit the LDS (or the channel count is no multiple of 19): the caller takes the two-kernel form.
+// uw16 / uw32: extents for 16- and 32-column tiles; tx_force (LWP_MS_TX): 16 | 32, 0 = choose.
+hipError_t launch_multiscale_fused(const MapView& src, int N, int C, int ratio, int crop_top, int crop_left, const int* xi, const float* xw,
+                                   const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum,
+                                   int uh_max, int uw16, int uw32, int tx_force, hipStream_t s, bool* used) {
+    *used = false;
+    constexpr int CG = 19;
+    if ((ratio != 4 && ratio != 8) || C % CG != 0 || uh_max <= 0 || uw16 <= 0) return hipSuccess;
+    // 32-column tiles while the tile stays small (magnifying resizes: half the workgroups, less halo — scale 0.5: 671 -> 543 us per
+    // 32 x 19 maps); from 1 : 1 on the wide tile costs workgroups per CU (scale 1: 812 -> 1037 us) and 16 columns stay
+    bool wide = uw32 > 0 && uw32 * CG <= 768 && (size_t)uh_max * (uw32 + 32) * CG * sizeof(float) <= 40 * 1024;
+    if (tx_force == 16) wide = false;
+    if (tx_force == 32) wide = true;
+#define MSF(R_, TX_) launch_multiscale_fused_t<R_, CG, TX_>(src, N, C, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, uh_max, TX_ == 32 ? uw32 : uw16, s, used)
+    if (wide) {
+        hipError_t e = ratio == 4 ? MSF(4, 32) : MSF(8, 32);
+        if (e != hipSuccess || *used) return e;
+    }
+    return ratio == 4 ? MSF(4, 16) : MSF(8, 16);
+#undef MSF
 }
 
 __global__ void __launch_bounds__(256) threshold_kernel(float* m, int64_t n) {

@@ -24,8 +24,11 @@ for name, h, w, pad in geos:
         print("scale %%s C=%%2d: %%8.0f us  (%%.2f TB/s of accumulator traffic)" %% (name, C, us, 2 * acc.numel() * 4 / us / 1e6))
 print("scales 0.5 + 1 + 1.5, both maps: %%.2f ms" %% (tot / 1e3))
 ''' % ROOT
-batch = sys.argv[1] if len(sys.argv) > 1 else "32"
-for tag, env in (("fused", {}), ("two kernels (LWP_MS_FUSED=0)", {"LWP_MS_FUSED": "0"})):
+batch = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].isdigit() else "32"
+cfgs = [("fused", {}), ("two kernels (LWP_MS_FUSED=0)", {"LWP_MS_FUSED": "0"})]
+if "--tx" in sys.argv:
+    cfgs = [("fused, 16-column tiles", {"LWP_MS_TX": "16"}), ("fused, 32-column tiles", {"LWP_MS_TX": "32"})] + cfgs
+for tag, env in cfgs:
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "-c", CHILD, batch], capture_output=True, text=True, env=e, timeout=600)
     print("== " + tag); print(r.stdout if r.returncode == 0 else (r.stderr or r.stdout)[-800:])
