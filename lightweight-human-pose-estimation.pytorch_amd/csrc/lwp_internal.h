@@ -108,6 +108,7 @@ struct Tuning {
     int host_fetch_dma = -1;                                       // LWP_HOST_FETCH_DMA ("1": host frames by hipMemcpyAsync instead of the fetch kernel)
     int ms_tx = 0;                                                 // LWP_MS_TX (16 | 32: tile width of the fused multi-scale kernel; 0 = choose)
     int ms_fused = -1;                                             // LWP_MS_FUSED ("0": multi-scale step as up-sample + resize kernels)
+    int heads_f32_lds = -1;                                        // LWP_HEADS_F32_LDS ("0": the f32 stage heads above 4096 pixels as two GEMMs)
     int post_nchw = -1;                                            // LWP_POST_NCHW (f32: "0" = grouping reads the NHWC concat buffer in place)
     int heads_f32_max_m = 0;                                       // LWP_HEADS_F32_MAXM (tests: force the fused fp32 head pair at larger M)
 };

@@ -1701,18 +1701,194 @@ __global__ void __launch_bounds__(NW * 64) heads_f32_kernel(HeadsParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------- stage heads at large M, weights through LDS
+// The same pair (hidden values never leave the lane's registers, same MFMA operand conventions as heads_f32_kernel) for M > 4096:
+// there every 16-pixel workgroup of the kernel above would stream the pair's whole weights (768 KB for the initial stage) from L2,
+// and the two-GEMM form writes and reads the hidden tensor instead (494 MB per direction at batch 32: 335 + 160 us for the initial
+// stage, 91 + 54 for a refinement stage).  Here a workgroup owns 64 PT pixels (4 waves x PT 16-pixel tiles) and walks the hidden
+// dimension in chunks of 32: the chunk's W0 rows [32][128] and W1 columns [64][32] are staged ONCE per workgroup in LDS (double
+// buffered, requested a chunk ahead into registers), every fragment read feeds PT MFMAs, and each wave accumulates all 64 (57 used)
+// outputs of its own pixels over all chunks — no cross-wave reduction.  k-slot (step 4u + c, lane group q) of GEMM 1 is input
+// channel 16u + 4q + c: a lane's eight fragments are 16-byte reads one slot apart between the lane groups, and with rows of
+// 128 + 8 / 32 + 8 floats every ds_read_b128 is bank-conflict free (slot = row x stride + q, stride = 2 mod 4: see DWPW_APAD).
+constexpr int HL_HC = 32, HL_LD0 = 128 + 8, HL_LD1 = HL_HC + 8;
+template <int PT>
+__global__ void __launch_bounds__(256) heads_f32_lds_kernel(HeadsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float hl_sm[];
+    float* W0s = hl_sm;                                              // [2][HL_HC][HL_LD0]
+    float* W1s = W0s + 2 * HL_HC * HL_LD0;                           // [2][64][HL_LD1]
+    float* B0s = W1s + 2 * 64 * HL_LD1;                              // [hidden]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int M = p.N * p.H * p.W;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    }
+    int mr[PT];
+    bool mok[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) { mr[i] = bid * (64 * PT) + (wave * PT + i) * 16 + i16; mok[i] = mr[i] < M; }
+    const int nch = p.hidden / HL_HC;
+    const float* in = (const float*)p.in;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)((int64_t)M * p.in_ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w0r = __builtin_amdgcn_make_buffer_rsrc((void*)p.w0, 0, p.hidden * 128 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, 64 * p.hidden * 4, 0x00020000);
+    auto ld = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, unsigned soff) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)); };
+    // weight staging: W0 chunk = 32 rows x 512 B (4 x 16 B per thread), W1 chunk = 64 rows x 128 B (2 x 16 B per thread)
+    f32x4 st0[4], st1[2];
+    auto request = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ch = tid + u * 256, row = ch >> 5, col = (ch & 31) * 4;
+            st0[u] = ld(w0r, (unsigned)(row * 128 + col) * 4u, (unsigned)c * (HL_HC * 128 * 4));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ch = tid + u * 256, row = ch >> 3, col = (ch & 7) * 4;
+            st1[u] = ld(w1r, (unsigned)(row * p.hidden + col) * 4u, (unsigned)c * (HL_HC * 4));
+        }
+    };
+    auto land = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ch = tid + u * 256, row = ch >> 5, col = (ch & 31) * 4;
+            *(f32x4*)(W0s + (buf * HL_HC + row) * HL_LD0 + col) = st0[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ch = tid + u * 256, row = ch >> 3, col = (ch & 7) * 4;
+            *(f32x4*)(W1s + (buf * 64 + row) * HL_LD1 + col) = st1[u];
+        }
+    };
+    request(0);
+    // the wave's activations: fragment u of pixel m = x[m][16 u + 4 q .. + 3]
+    f32x4 xf[PT][8];
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xf[i][u] = ld(xr, mok[i] ? (unsigned)((mr[i] * p.in_ld + 16 * u + 4 * q) * 4) : 0x80000000u, 0);
+    for (int i = tid * 4; i < p.hidden; i += 256 * 4) *(f32x4*)(B0s + i) = *(const f32x4*)(p.b0 + i);
+    land(0);
+    __syncthreads();
+
+    f32x4 acc2[PT][4];
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc2[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // block-diagonal second conv (p.out_split > 0: merged heat / PAF pair): hidden channels < hsplit feed outputs < out_split only
+    const int hsplit = p.out_split > 0 ? p.hidden / 2 : p.hidden;
+    const int t_last_lo = p.out_split > 0 ? (p.out_split + 15) / 16 : 4;
+    const int t_first_hi = p.out_split > 0 ? p.out_split / 16 : 0;
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        request(c + 1 < nch ? c + 1 : c);                            // unconditional (the last chunk again): exact vmcnt counting
+        __builtin_amdgcn_sched_barrier(0);                           // keep the requests ahead of the chunk's MFMAs
+#pragma unroll
+        for (int j = 0; j < HL_HC / 16; ++j) {                       // the chunk's two 16-channel hidden tiles
+            const float* w0 = W0s + (buf * HL_HC + j * 16 + i16) * HL_LD0 + 4 * q;
+            f32x4 wv[8];                                             // all eight fragment reads in flight before the first MFMA
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = *(const f32x4*)(w0 + 16 * u);
+            const f32x4 b0 = *(const f32x4*)(B0s + c * HL_HC + j * 16 + 4 * q);
+            const int ht16 = (c * HL_HC + j * 16);                   // first hidden channel of the tile (wave-uniform)
+            const bool first_half = ht16 < hsplit;
+            const int t_lo = first_half ? 0 : t_first_hi, t_hi = first_half ? t_last_lo : 4;
+            f32x4 w1v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w1v[t] = *(const f32x4*)(W1s + (buf * 64 + t * 16 + i16) * HL_LD1 + j * 16 + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc1[PT];
+#pragma unroll
+            for (int i = 0; i < PT; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][cc], xf[i][u][cc], acc1[i], 0, 0, 0);
+            f32x4 hv[PT];
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[i][r] = fmaxf(acc1[i][r] + b0[r], 0.f);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < t_lo || t >= t_hi) continue;                 // scalar branch around whole MFMA groups
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < PT; ++i) acc2[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1v[t][r], hv[i][r], acc2[i][t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nch) land(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane (pixel i16, q) holds output channels 16 t + 4 q + r
+    float* out = (float*)p.out;
+    const int HW = p.H * p.W;
+    const int c0 = p.out_split > 0 ? p.out_split : p.cout;
+    const bool out_vec = ((p.out_ld & 3) == 0) && ((((uintptr_t)out) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        if (!mok[i]) continue;
+        const int m = mr[i];
+        const int img = m / HW, pix = m - img * HW;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = 16 * t + 4 * q;
+            if (n >= p.cout) continue;
+            f32x4 v = acc2[i][t];
+            v += *(const f32x4*)(p.b1 + n);
+            if (out_vec && n + 3 < p.cout) *(f32x4*)(out + (int64_t)m * p.out_ld + n) = v;
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.cout) out[(int64_t)m * p.out_ld + n + r] = v[r];
+            }
+            if (p.out_nchw || p.out_nchw2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = n + r;
+                    if (ch >= p.cout) continue;
+                    if (ch < c0) { if (p.out_nchw) p.out_nchw[((int64_t)img * c0 + ch) * HW + pix] = v[r]; }
+                    else if (p.out_nchw2) p.out_nchw2[((int64_t)img * (p.cout - c0) + (ch - c0)) * HW + pix] = v[r];
+                }
+            }
+        }
+    }
+}
+
 bool heads_f32_supported(int cin_pad, int hidden, int cout_pad, int64_t M, const Tuning* tune) {
     const int64_t max_m = (tune && tune->heads_f32_max_m > 0) ? tune->heads_f32_max_m : 4096;     // LWP_HEADS_F32_MAXM (tests)
     // every 16-pixel workgroup streams all of W0 and W1 (768 KB for the initial stage): only while the grid is ONE round of the
     // chip (measured at batch 2, 472 workgroups: 57 us against 27 + 17 for the two GEMMs; batch 1: 29.5 against 18.6 + 9.3 with
     // two launch floors less)
-    return cin_pad == 128 && hidden % 16 == 0 && hidden >= 128 && hidden <= 4096 && cout_pad == 64 && M <= max_m;
+    if (!(cin_pad == 128 && hidden % 16 == 0 && hidden >= 128 && hidden <= 4096 && cout_pad == 64)) return false;
+    if (M <= max_m) return true;
+    // larger M: the LDS-staged form (LWP_HEADS_F32_LDS=0: the two GEMMs, A/B)
+    return hidden % HL_HC == 0 && !(tune && tune->heads_f32_lds == 0);
 }
 
 hipError_t launch_heads_f32(const HeadsParams& p, hipStream_t s) {
     constexpr int NW = 8;
     const int64_t M = (int64_t)p.N * p.H * p.W;
     if (M * p.in_ld * 4 >= (1ll << 31) || (p.in_ld & 3)) return hipErrorInvalidValue;
+    const int64_t max_m = (p.tune && p.tune->heads_f32_max_m > 0) ? p.tune->heads_f32_max_m : 4096;
+    if (M > max_m) {
+        constexpr int PT = 2;
+        if (M >= (1ll << 31) - 64 * PT) return hipErrorInvalidValue;
+        const size_t lds2 = (size_t)(2 * HL_HC * HL_LD0 + 2 * 64 * HL_LD1 + p.hidden) * sizeof(float);
+        static LdsAttrOnce attr;
+        hipError_t e = attr.ensure((const void*)heads_f32_lds_kernel<PT>, 96 * 1024);
+        if (e != hipSuccess) return e;
+        LWP_VARIANT(p, "heads_f32_lds<%d>", PT);
+        hipLaunchKernelGGL(heads_f32_lds_kernel<PT>, dim3((unsigned)((M + 64 * PT - 1) / (64 * PT))), dim3(256), lds2, s, p);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)NW * 4 * 64 * 4 * sizeof(float);
     LWP_VARIANT(p, "heads_f32<%d>", NW);
     hipLaunchKernelGGL(heads_f32_kernel<NW>, dim3((unsigned)((M + 15) / 16)), dim3(NW * 64), lds, s, p);
@@ -1744,7 +1920,7 @@ Tuning tuning_from_env() {
     geti("LWP_GEMMH_DEBUG", &t.gemmh_debug);
     if (const char* e = getenv("LWP_GEMMH")) t.has_gemmh = sscanf(e, "%d,%d,%d,%d", &t.gemmh[0], &t.gemmh[1], &t.gemmh[2], &t.gemmh[3]) == 4;
     digit("LWP_UPSAMPLE_TILED", &t.upsample_tiled);
-    digit("LWP_PEAK_TILE", &t.peak_tile); digit("LWP_PAIR_FORM", &t.pair_form); digit("LWP_POST_NCHW", &t.post_nchw); digit("LWP_MS_FUSED", &t.ms_fused); geti("LWP_MS_TX", &t.ms_tx); digit("LWP_HOST_FETCH_DMA", &t.host_fetch_dma); geti("LWP_DWPW_LDS_PAD", &t.dwpw_lds_pad_kb);
+    digit("LWP_PEAK_TILE", &t.peak_tile); digit("LWP_PAIR_FORM", &t.pair_form); digit("LWP_POST_NCHW", &t.post_nchw); digit("LWP_HEADS_F32_LDS", &t.heads_f32_lds); digit("LWP_MS_FUSED", &t.ms_fused); geti("LWP_MS_TX", &t.ms_tx); digit("LWP_HOST_FETCH_DMA", &t.host_fetch_dma); geti("LWP_DWPW_LDS_PAD", &t.dwpw_lds_pad_kb);
     geti("LWP_HEADS_F32_MAXM", &t.heads_f32_max_m);
     geti("LWP_MAX_FRAMES_PER_PASS", &t.max_frames_per_pass);
     return t;

@@ -1071,6 +1071,42 @@ def test_fp32_fused_head_pair_matches_the_two_gemm_form(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_fp32_lds_staged_head_pair_forced_at_small_ragged_sizes(monkeypatch):
+    """heads_f32_lds_kernel (M > 4096: 128-pixel workgroups, the pair's weights staged once per workgroup in LDS in chunks of 32
+    hidden channels, hidden values in registers, merged heat / PAF pair with the block-diagonal second conv) forced at
+    M = 2 x 12 x 19 = 456 pixels (four workgroups, the last one ragged) through LWP_HEADS_F32_MAXM=16: initial stage (hidden 2 x 512)
+    and two refinement stages (hidden 2 x 128) against the two GEMM launches (LWP_FUSE_HEADS=0), the 16-pixel form and the oracle."""
+    sd = synth.make_state_dict(2, seed=3)
+    x = net_input(2, 92, 150, seed=412)[:, :, :91, :149].copy()
+    ref = net_ref.forward(sd, torch.from_numpy(x), 2)
+
+    def run(fuse, maxm):
+        monkeypatch.setenv("LWP_FUSE_HEADS", fuse)
+        if maxm:
+            monkeypatch.setenv("LWP_HEADS_F32_MAXM", maxm)
+        else:
+            monkeypatch.delenv("LWP_HEADS_F32_MAXM", raising=False)
+        net = PoseEstimationWithMobileNet(num_refinement_stages=2)
+        load_state(net, {"state_dict": sd})
+        net.eval().cuda()
+        names = [i for i in net.engine.layers() if i["name"].endswith(".heads.1")]
+        taps = {i["name"]: net.engine.debug_layer_output(x, i["index"]) for i in names}
+        return net(x), taps, {i["name"]: net.engine.layer_variant(i["index"]) for i in names}
+    lds, taps_l, var_l = run("1", "16")
+    small, taps_s, var_s = run("1", "")
+    plain, taps_p, var_p = run("0", "")
+    assert len(var_l) == 3 and all(v.startswith("heads_f32_lds<") for v in var_l.values()), var_l
+    assert all(v.startswith("heads_f32<") for v in var_s.values()), var_s
+    for f, g, q, r in zip(lds, small, plain, ref):
+        sc = max(1.0, float(r.abs().max()))
+        assert np.abs(f - r.numpy()).max() <= NET_TOL * sc
+        assert np.abs(f - q).max() <= NET_TOL * sc and np.abs(f - g).max() <= NET_TOL * sc
+    for nm in taps_l:
+        sc = max(1.0, float(np.abs(taps_p[nm]).max()))
+        assert np.abs(taps_l[nm] - taps_p[nm]).max() <= NET_TOL * sc, nm
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C,NH,NP", [(96, 19, 38), (64, 17, 30)])
 def test_fp32_non_default_channel_counts_match_the_oracle(C, NH, NP):
     """The constructor's other arguments (with_mobilenet.py:89: num_channels, num_heatmaps, num_pafs) take different paths
