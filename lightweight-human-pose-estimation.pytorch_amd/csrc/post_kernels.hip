@@ -279,8 +279,11 @@ hipError_t launch_resize_accum(const float* src, int N, int Hs, int Ws, int C, i
 // The value of a (row, column) pair of every pass does not depend on which output pixel asks for it, so the bits are those of the
 // two-kernel form (tested against it and against the oracle).  HBM traffic: the accumulator's read + write.
 constexpr int MS_TY = 8;
-template <int R, int CG, int MS_TX>      // MS_TX = 16 | 32 output columns per workgroup (32 while the tile's x R columns still fit three items per thread)
-__global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int C, int crop_top, int crop_left, const int* __restrict__ xi,
+// K1 / K2: (column, channel) items per thread and row of the x R passes / of the output passes.  The tile width MS_TX is a run-time
+// value chosen per geometry so that MS_TX * CG and the tile's x R extent * CG sit just under a multiple of 256 (13 columns at scale
+// 1.5: 247 and 456 items, K = 1 / 2 at 96 % / 89 % of the lanes — 16 columns gave 304 and 532: K = 2 / 3 at 59 % / 69 %).
+template <int R, int CG, int K1, int K2>
+__global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int C, int MS_TX, int crop_top, int crop_left, const int* __restrict__ xi,
                                                                const float* __restrict__ xw, const int* __restrict__ yi, const float* __restrict__ yw,
                                                                int dst_h, int dst_w, float divisor, int init, float* __restrict__ accum,
                                                                int lo_hz_floats) {
@@ -304,7 +307,6 @@ __global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int 
     const float* base = src.base + (int64_t)n * src.ns + (int64_t)c0 * src.cs;
     // the accumulator values this thread will update are requested NOW: their latency hides behind the four passes (at the
     // magnifying scales a workgroup's passes are short and the read-modify-write at the end was an exposed round trip)
-    constexpr int K2 = (MS_TX * CG + 255) / 256;                       // items per thread and output row
     const int W2 = (x1 - x0) * CG;
     int xl2[K2], c2[K2];
     float accv[MS_TY][K2];
@@ -339,7 +341,6 @@ __global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int 
     // A thread's items of a row — (column, channel) pairs tid, tid + 256, ... — are the same for every row of a pass, so their tap
     // offsets and weights are computed ONCE per pass (the first version redid the index arithmetic and the table loads per row and
     // item: ~300 instructions per output element; ~170 now, most of them the up-sampled values of the tile's halo).
-    constexpr int K1 = 3;                                              // items per thread and row: UW * CG <= 768 (host-checked)
     const int W1 = UW * CG;
     {                                                                  // up-sampling, horizontal
         int off[K1];
@@ -429,7 +430,7 @@ __global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int 
         }
     }
 }
-// host: x R rows / columns the largest tile of a geometry touches, for tiles of MS_TY x tx output pixels (called once per geometry)
+// host: x R rows / columns the largest tile of a geometry touches, for tiles of MS_TY x tx output pixels
 void multiscale_fused_extent(const int* xi, const int* yi, int dst_h, int dst_w, int tx, int* uh_max, int* uw_max) {
     *uh_max = *uw_max = 0;
     for (int y0 = 0; y0 < dst_h; y0 += MS_TY) {
@@ -441,44 +442,62 @@ void multiscale_fused_extent(const int* xi, const int* yi, int dst_h, int dst_w,
         *uw_max = std::max(*uw_max, b - a + 1);
     }
 }
-template <int R, int CG, int TX>
-static hipError_t launch_multiscale_fused_t(const MapView& src, int N, int C, int crop_top, int crop_left, const int* xi, const float* xw,
+// host, once per geometry: the tile width with the fewest thread-iterations over the whole map (19-channel groups), its extents
+void multiscale_fused_plan(const int* xi, const int* yi, int dst_h, int dst_w, int R, int* tx_best, int* uh_max, int* uw_max) {
+    constexpr int CG = 19;
+    double best = 1e300;
+    *tx_best = 0; *uh_max = 0; *uw_max = 0;
+    for (int tx = 8; tx <= 40; ++tx) {
+        int uh = 0, uw = 0;
+        multiscale_fused_extent(xi, yi, dst_h, dst_w, tx, &uh, &uw);
+        const int k1 = (uw * CG + 255) / 256, k2 = (tx * CG + 255) / 256;
+        const int lh = (uh - 1) / R + 6, lw = (uw - 1) / R + 6;
+        const size_t lo_hz = (size_t)(lh * lw + lh * uw) * CG, h2 = (size_t)uh * tx * CG;
+        const size_t lds = ((lo_hz > h2 ? lo_hz : h2) + (size_t)uh * uw * CG) * sizeof(float);
+        if (k1 > 3 || k2 > 3 || k2 > k1 || lh * lw > 256 || lds > 64 * 1024) continue;
+        // iterations of a workgroup (rows x items per thread of the four passes) + a fixed part for its barriers and fetches
+        const double wg = (double)lh * k1 + (double)uh * k1 + (double)uh * k2 + (double)MS_TY * k2 + 12.0;
+        // workgroups per CU by LDS: measured at scale 2, 12 columns (55 KB, two per CU) run 1835 us against 1456 for 11 columns (51 KB, three)
+        const int occ = (int)((160 * 1024) / (lds + 512));
+        const double cost = wg * ((dst_w + tx - 1) / tx) * (occ >= 4 ? 1.0 : occ == 3 ? 1.05 : occ == 2 ? 1.4 : 2.2);
+        if (cost < best) { best = cost; *tx_best = tx; *uh_max = uh; *uw_max = uw; }
+    }
+}
+template <int R, int CG, int K1, int K2>
+static hipError_t launch_multiscale_fused_t(const MapView& src, int N, int C, int tx, int crop_top, int crop_left, const int* xi, const float* xw,
                                             const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum,
-                                            int uh_max, int uw_max, hipStream_t s, bool* used) {
+                                            int uh_max, int uw_max, hipStream_t s) {
     // low-resolution extent of a run of U rows starting anywhere: at most (U - 1) / R + 1 distinct q, + 1 for the phase, + 4 taps
     const int lh_max = (uh_max - 1) / R + 6, lw_max = (uw_max - 1) / R + 6;
-    if (lh_max * lw_max > 256 || uw_max * CG > 768) return hipSuccess;   // one thread per low-resolution pixel; three items per thread and x R row
-    const size_t lo_hz = (size_t)(lh_max * lw_max + lh_max * uw_max) * CG, h2 = (size_t)uh_max * TX * CG;
+    const size_t lo_hz = (size_t)(lh_max * lw_max + lh_max * uw_max) * CG, h2 = (size_t)uh_max * tx * CG;
     const size_t a = lo_hz > h2 ? lo_hz : h2, lds = (a + (size_t)uh_max * uw_max * CG) * sizeof(float);
-    if (lds > 96 * 1024) return hipSuccess;
     static LdsAttrOnce attr;
-    hipError_t e = attr.ensure((const void*)multiscale_fused_kernel<R, CG, TX>, 96 * 1024);
+    hipError_t e = attr.ensure((const void*)multiscale_fused_kernel<R, CG, K1, K2>, 96 * 1024);
     if (e != hipSuccess) return e;
-    *used = true;
-    const dim3 grid(((dst_w + TX - 1) / TX) * ((dst_h + MS_TY - 1) / MS_TY), C / CG, N);
-    hipLaunchKernelGGL((multiscale_fused_kernel<R, CG, TX>), grid, dim3(256), lds, s, src, C, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
+    const dim3 grid(((dst_w + tx - 1) / tx) * ((dst_h + MS_TY - 1) / MS_TY), C / CG, N);
+    hipLaunchKernelGGL((multiscale_fused_kernel<R, CG, K1, K2>), grid, dim3(256), lds, s, src, C, tx, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
     return hipGetLastError();
 }
-// *used = false: the geometry does not fit the LDS (or the channel count is no multiple of 19): the caller takes the two-kernel form.
-// uw16 / uw32: extents for 16- and 32-column tiles; tx_force (LWP_MS_TX): 16 | 32, 0 = choose.
+// *used = false: the geometry does not fit (or the channel count is no multiple of 19): the caller takes the two-kernel form.
+// tx / uh_max / uw_max: the geometry's plan (multiscale_fused_plan, or multiscale_fused_extent for a forced width).
 hipError_t launch_multiscale_fused(const MapView& src, int N, int C, int ratio, int crop_top, int crop_left, const int* xi, const float* xw,
                                    const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum,
-                                   int uh_max, int uw16, int uw32, int tx_force, hipStream_t s, bool* used) {
+                                   int tx, int uh_max, int uw_max, hipStream_t s, bool* used) {
     *used = false;
     constexpr int CG = 19;
-    if ((ratio != 4 && ratio != 8) || C % CG != 0 || uh_max <= 0 || uw16 <= 0) return hipSuccess;
-    // 32-column tiles while the tile stays small (magnifying resizes: half the workgroups, less halo — scale 0.5: 671 -> 543 us per
-    // 32 x 19 maps); from 1 : 1 on the wide tile costs workgroups per CU (scale 1: 812 -> 1037 us) and 16 columns stay
-    bool wide = uw32 > 0 && uw32 * CG <= 768 && (size_t)uh_max * (uw32 + 32) * CG * sizeof(float) <= 40 * 1024;
-    if (tx_force == 16) wide = false;
-    if (tx_force == 32) wide = true;
-#define MSF(R_, TX_) launch_multiscale_fused_t<R_, CG, TX_>(src, N, C, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, uh_max, TX_ == 32 ? uw32 : uw16, s, used)
-    if (wide) {
-        hipError_t e = ratio == 4 ? MSF(4, 32) : MSF(8, 32);
-        if (e != hipSuccess || *used) return e;
-    }
-    return ratio == 4 ? MSF(4, 16) : MSF(8, 16);
+    if ((ratio != 4 && ratio != 8) || C % CG != 0 || tx <= 0 || uh_max <= 0 || uw_max <= 0) return hipSuccess;
+    const int k1 = (uw_max * CG + 255) / 256, k2 = (tx * CG + 255) / 256;
+    const int lh_max = (uh_max - 1) / ratio + 6, lw_max = (uw_max - 1) / ratio + 6;
+    const size_t lo_hz = (size_t)(lh_max * lw_max + lh_max * uw_max) * CG, h2 = (size_t)uh_max * tx * CG;
+    if (k1 > 3 || k2 > k1 || lh_max * lw_max > 256 || ((lo_hz > h2 ? lo_hz : h2) + (size_t)uh_max * uw_max * CG) * sizeof(float) > 96 * 1024) return hipSuccess;
+    *used = true;
+#define MSF(R_, K1_, K2_) launch_multiscale_fused_t<R_, CG, K1_, K2_>(src, N, C, tx, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, uh_max, uw_max, s)
+#define MSF_R(K1_, K2_) if (k1 == K1_ && k2 == K2_) return ratio == 4 ? MSF(4, K1_, K2_) : MSF(8, K1_, K2_);
+    MSF_R(1, 1) MSF_R(2, 1) MSF_R(2, 2) MSF_R(3, 1) MSF_R(3, 2) MSF_R(3, 3)
+#undef MSF_R
 #undef MSF
+    *used = false;
+    return hipSuccess;
 }
 
 __global__ void __launch_bounds__(256) threshold_kernel(float* m, int64_t n) {

@@ -27,7 +27,7 @@ print("scales 0.5 + 1 + 1.5, both maps: %%.2f ms" %% (tot / 1e3))
 batch = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].isdigit() else "32"
 cfgs = [("fused", {}), ("two kernels (LWP_MS_FUSED=0)", {"LWP_MS_FUSED": "0"})]
 if "--tx" in sys.argv:
-    cfgs = [("fused, 16-column tiles", {"LWP_MS_TX": "16"}), ("fused, 32-column tiles", {"LWP_MS_TX": "32"})] + cfgs
+    cfgs = [("fused, %s-column tiles" % t, {"LWP_MS_TX": t}) for t in ("11", "13", "16", "26", "32")] + cfgs
 for tag, env in cfgs:
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "-c", CHILD, batch], capture_output=True, text=True, env=e, timeout=600)
