@@ -66,6 +66,7 @@ python3 tools/post_sweep.py 32 fp32 ";" > $OUT/post_chain_b32_fp32.txt 2>/dev/nu
 python3 tools/post_sweep.py 32 bf16 ";" > $OUT/post_chain_b32_bf16.txt 2>/dev/null
 python3 tools/post_sweep.py 1 fp32 ";" > $OUT/post_chain_b1_fp32.txt 2>/dev/null
 python3 tools/u8_probe.py > $OUT/u8_boundary_b1_fp32.txt 2>/dev/null
+python3 tools/ms_bench.py 32 > $OUT/multiscale_step_b32.txt 2>/dev/null
 echo "tables done"
 python3 bench.py > $OUT/bench_default.json 2>/dev/null
 # 4. multi-rank rehearsal of the N > 1 bench path on this ONE card (real engines, gloo instead of RCCL, 4 ranks: the box allows
