@@ -1066,19 +1066,23 @@ __global__ void __launch_bounds__(256) score_pairs_kernel(MapView paf, int ratio
     const int* xa = ws.kpt_xy + (int64_t)(n * 18 + ta) * kcap * 2;
     const int* xb = ws.kpt_xy + (int64_t)(n * 18 + tb) * kcap * 2;
     unsigned long long* fl = ws.flags + n * 4;
-    const int sub = threadIdx.x & 15;
+    // 12 lanes per pair (11 used: ten samples + the mid-point), five pairs per wave, lanes 60-63 idle: 92 % of the lanes carry a
+    // sample (16 lanes per pair: 69 %)
+    constexpr int SP_LANES = 12, SP_PPW = 5, SP_PPB = 4 * SP_PPW;      // lanes per pair, pairs per wave, pairs per workgroup and iteration
     const int lane = threadIdx.x & 63;
-    const int grp0 = lane & ~15;                                   // first lane of this 16-lane group
+    const int pw = lane / SP_LANES;                                    // pair slot within the wave (5 = the idle lanes)
+    const int sub = lane - pw * SP_LANES;
+    const int grp0 = (pw < SP_PPW ? pw : SP_PPW - 1) * SP_LANES;   // first lane of this pair's group (idle lanes: a valid source for the shuffles)
     // the two "first pair whose mid-point test failed / passed" orders are minima over ALL pairs of the frame: every pair used to
     // issue a 64-bit atomicMin on the frame's flag word — ~3700 same-address atomics per frame, which serialise at the memory side
     // (the dominant cost of this kernel at batch 32).  They are reduced in LDS first: one global atomic per workgroup and flag.
     __shared__ unsigned long long s_min[2];
     if (threadIdx.x < 2) s_min[threadIdx.x] = ~0ull;
     __syncthreads();
-    const int npair_iters = (npairs + SP_BLOCKS * 16 - 1) / (SP_BLOCKS * 16);
+    const int npair_iters = (npairs + SP_BLOCKS * SP_PPB - 1) / (SP_BLOCKS * SP_PPB);
     for (int itp = 0; itp < npair_iters; ++itp) {                  // uniform trip count: shuffles need all lanes
-        const int p = (itp * SP_BLOCKS + blockIdx.x) * 16 + (threadIdx.x >> 4);
-        const bool valid = p < npairs;
+        const int p = (itp * SP_BLOCKS + blockIdx.x) * SP_PPB + (threadIdx.x >> 6) * SP_PPW + pw;
+        const bool valid = pw < SP_PPW && p < npairs;
         const int pp = valid ? p : 0;
         const int i = pp / nb, j = pp - i * nb;
         const int ax = xa[i * 2], ay = xa[i * 2 + 1], bx = xb[j * 2], by = xb[j * 2 + 1];
