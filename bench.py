@@ -571,13 +571,16 @@ def measure_extras(out, args, eng, engines, net, sd, x, x_np, step, run_steps, l
             # the network of the next ones); every step is still a complete pass with its results on the host
             engs = replicas(eng2, dt_, int(os.environ.get("LWP_BENCH_BN_STREAMS", "2")))
             pipelined_steps(engs, xb, 4)
+            # blocks long enough that the fill and the drain of the pipeline (four batches in flight) are a few per cent of a block:
+            # 8-step blocks read 5-6 % below the sustained rate the headline loop measures on the same engines
+            kb = 32 if b >= 32 else 64
             ts = []
             for _ in range(3):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                pipelined_steps(engs, xb, 8)
+                pipelined_steps(engs, xb, kb)
                 torch.cuda.synchronize()
-                ts.append((time.perf_counter() - t1) / 8)
+                ts.append((time.perf_counter() - t1) / kb)
             t2 = sorted(ts)[1]
             dms = eng2.time_pipeline(xb, 5, what=1) / 5.0
             ent = {"frames_per_s": b / t2, "ms_per_step": t2 * 1e3, "protocol": "%d engine stream(s) x 2 result slots (as the headline)" % len(engs),
