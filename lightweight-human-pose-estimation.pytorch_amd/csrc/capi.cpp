@@ -36,7 +36,7 @@ struct lwp_context {
     std::vector<size_t> d_outs_bytes;
     float* d_tmp = nullptr; size_t d_tmp_bytes = 0;     // generic device staging (upsample / extract / group)
     float* d_tmp2 = nullptr; size_t d_tmp2_bytes = 0;
-    struct ResizeTab { int cw, ch, dw, dh; void* d; double ratio; int uh_max = 0, uw_max = 0, tx = 0, up_ratio = 0; };   // cubic resize tables of the multi-scale path, kept on the device (+ the fused kernel's tile extents)
+    struct ResizeTab { int cw, ch, dw, dh; void* d; double ratio; int uh_max = 0, uw_max = 0, tx = 0, up_ratio = 0, tx4 = 0, uh4 = 0, uw4 = 0; };   // cubic resize tables of the multi-scale path, kept on the device (+ the fused kernel's tile extents)
     std::vector<ResizeTab> resize_tabs;                  // (a per-call upload went through SDMA queues: multi-ms stalls on some boxes)
     std::vector<ResizeTab> scale_tabs;                   // image-side tables of lwp_preprocess_scaled_u8: (W, H, dw, dh, ratio)
     unsigned char* d_imgs = nullptr; size_t d_imgs_bytes = 0;   // uint8 frame batch staging (host frames of the multi-scale path)
@@ -745,9 +745,11 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     // per-geometry tables, uploaded once (blocking copy) and kept: steady-state calls issue no host->device copy
     const size_t nx = (size_t)dst_w * 4, ny = (size_t)dst_h * 4;
     void* d_tabs = nullptr;
-    int uh_max = 0, uw_max = 0, ms_tx = 0;
+    int uh_max = 0, uw_max = 0, ms_tx = 0, tx4 = 0, uh4 = 0, uw4 = 0;
     for (const auto& rt : h->resize_tabs)
-        if (rt.cw == cw && rt.ch == ch && rt.dw == dst_w && rt.dh == dst_h && rt.up_ratio == up_ratio) { d_tabs = rt.d; uh_max = rt.uh_max; uw_max = rt.uw_max; ms_tx = rt.tx; break; }
+        if (rt.cw == cw && rt.ch == ch && rt.dw == dst_w && rt.dh == dst_h && rt.up_ratio == up_ratio) {
+            d_tabs = rt.d; uh_max = rt.uh_max; uw_max = rt.uw_max; ms_tx = rt.tx; tx4 = rt.tx4; uh4 = rt.uh4; uw4 = rt.uw4; break;
+        }
     if (!d_tabs) {
         std::vector<int> xi, yi;
         std::vector<float> xw, yw;
@@ -756,8 +758,10 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
         if (h->tune.ms_tx >= 8 && h->tune.ms_tx <= 40) {   // LWP_MS_TX: a forced tile width (tests, A/B)
             ms_tx = h->tune.ms_tx;
             multiscale_fused_extent(xi.data(), yi.data(), dst_h, dst_w, ms_tx, &uh_max, &uw_max);
+            tx4 = ms_tx; uh4 = uh_max; uw4 = uw_max;
         } else {
             multiscale_fused_plan(xi.data(), yi.data(), dst_h, dst_w, up_ratio, &ms_tx, &uh_max, &uw_max);
+            multiscale_fused_plan_v4(xi.data(), yi.data(), dst_h, dst_w, up_ratio, &tx4, &uh4, &uw4);
         }
         if (h->resize_tabs.size() >= 16) {               // bounded: drop the oldest geometry
             HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -770,7 +774,7 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
         HIP_TRY(h, hipMemcpy(t0 + nx * 4, xw.data(), nx * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(t0 + nx * 8, yi.data(), ny * 4, hipMemcpyHostToDevice));
         HIP_TRY(h, hipMemcpy(t0 + nx * 8 + ny * 4, yw.data(), ny * 4, hipMemcpyHostToDevice));
-        h->resize_tabs.push_back({cw, ch, dst_w, dst_h, d_tabs, 0.0, uh_max, uw_max, ms_tx, up_ratio});
+        h->resize_tabs.push_back({cw, ch, dst_w, dst_h, d_tabs, 0.0, uh_max, uw_max, ms_tx, up_ratio, tx4, uh4, uw4});
     }
     char* t = (char*)d_tabs;
     int* d_xi = (int*)t; t += nx * 4;
@@ -779,7 +783,11 @@ extern "C" int lwp_multiscale_accumulate(lwp_handle h, const float* maps, int ma
     float* d_yw = (float*)t;
     MapView v{d_src, (int64_t)C * hs * ws, (int64_t)ws, 1, (int64_t)hs * ws, hs, ws};
     bool fused = false;
-    if (h->tune.ms_fused != 0) {                             // LWP_MS_FUSED=0: the two-kernel form (A/B, tests)
+    if (h->tune.ms_fused != 0 && h->tune.ms_vec != 0) {      // four channels per lane (LWP_MS_VEC=0: the scalar fused kernel)
+        LAUNCH(h, KC_POST, launch_multiscale_fused_v4(v, N, C, up_ratio, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, init ? 1 : 0,
+                                                      d_acc, tx4, uh4, uw4, h->stream, &fused));
+    }
+    if (!fused && h->tune.ms_fused != 0) {                   // LWP_MS_FUSED=0: the two-kernel form (A/B, tests)
         LAUNCH(h, KC_POST, launch_multiscale_fused(v, N, C, up_ratio, pad[0], pad[1], d_xi, d_xw, d_yi, d_yw, dst_h, dst_w, (float)n_scales, init ? 1 : 0,
                                                    d_acc, ms_tx, uh_max, uw_max, h->stream, &fused));
     }

@@ -107,6 +107,7 @@ struct Tuning {
     int dwpw_lds_pad_kb = 0;                                       // LWP_DWPW_LDS_PAD (KB of unused LDS per workgroup of the bf16 fused blocks: occupancy experiments)
     int host_fetch_dma = -1;                                       // LWP_HOST_FETCH_DMA ("1": host frames by hipMemcpyAsync instead of the fetch kernel)
     int ms_tx = 0;                                                 // LWP_MS_TX (8..40: tile width of the fused multi-scale kernel; 0 = the geometry's plan)
+    int ms_vec = -1;                                               // LWP_MS_VEC ("0": the scalar fused multi-scale kernel)
     int ms_fused = -1;                                             // LWP_MS_FUSED ("0": multi-scale step as up-sample + resize kernels)
     int heads_f32_lds = -1;                                        // LWP_HEADS_F32_LDS ("0": the f32 stage heads above 4096 pixels as two GEMMs)
     int post_nchw = -1;                                            // LWP_POST_NCHW (f32: "0" = grouping reads the NHWC concat buffer in place)
@@ -277,6 +278,10 @@ void multiscale_fused_plan(const int* xi, const int* yi, int dst_h, int dst_w, i
 hipError_t launch_multiscale_fused(const MapView& src, int N, int C, int ratio, int crop_top, int crop_left, const int* xi, const float* xw,
                                    const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum,
                                    int tx, int uh_max, int uw_max, hipStream_t s, bool* used);
+void multiscale_fused_plan_v4(const int* xi, const int* yi, int dst_h, int dst_w, int R, int* tx_best, int* uh_max, int* uw_max);
+hipError_t launch_multiscale_fused_v4(const MapView& src, int N, int C, int ratio, int crop_top, int crop_left, const int* xi, const float* xw,
+                                      const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum,
+                                      int tx, int uh_max, int uw_max, hipStream_t s, bool* used);
 hipError_t launch_resize_accum(const float* src, int N, int Hs, int Ws, int C, int crop_top, int crop_left, const int* xi, const float* xw,
                                const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum, hipStream_t s);
 hipError_t launch_threshold_inplace(float* map, int64_t n, hipStream_t s);

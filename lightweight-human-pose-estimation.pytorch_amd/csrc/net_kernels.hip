@@ -1928,7 +1928,7 @@ Tuning tuning_from_env() {
     geti("LWP_GEMMH_DEBUG", &t.gemmh_debug);
     if (const char* e = getenv("LWP_GEMMH")) t.has_gemmh = sscanf(e, "%d,%d,%d,%d", &t.gemmh[0], &t.gemmh[1], &t.gemmh[2], &t.gemmh[3]) == 4;
     digit("LWP_UPSAMPLE_TILED", &t.upsample_tiled);
-    digit("LWP_PEAK_TILE", &t.peak_tile); digit("LWP_PAIR_FORM", &t.pair_form); digit("LWP_POST_NCHW", &t.post_nchw); digit("LWP_HEADS_F32_LDS", &t.heads_f32_lds); digit("LWP_MS_FUSED", &t.ms_fused); geti("LWP_MS_TX", &t.ms_tx); digit("LWP_HOST_FETCH_DMA", &t.host_fetch_dma); geti("LWP_DWPW_LDS_PAD", &t.dwpw_lds_pad_kb);
+    digit("LWP_PEAK_TILE", &t.peak_tile); digit("LWP_PAIR_FORM", &t.pair_form); digit("LWP_POST_NCHW", &t.post_nchw); digit("LWP_HEADS_F32_LDS", &t.heads_f32_lds); digit("LWP_MS_FUSED", &t.ms_fused); digit("LWP_MS_VEC", &t.ms_vec); geti("LWP_MS_TX", &t.ms_tx); digit("LWP_HOST_FETCH_DMA", &t.host_fetch_dma); geti("LWP_DWPW_LDS_PAD", &t.dwpw_lds_pad_kb);
     geti("LWP_HEADS_F32_MAXM", &t.heads_f32_max_m);
     geti("LWP_MAX_FRAMES_PER_PASS", &t.max_frames_per_pass);
     return t;

@@ -430,6 +430,153 @@ __global__ void __launch_bounds__(256) multiscale_fused_kernel(MapView src, int 
         }
     }
 }
+// Four channels per lane: the same four passes on 19-channel groups padded to 20 (five float4 per pixel in LDS; the pad lane
+// computes on zeros and is never stored).  One ds_read_b128 / ds_write_b128 and one address per FOUR values: ~9 instructions per
+// value instead of ~14.  A row of a pass has columns x 5 items, so 256 threads cover 256 / items ROWS per iteration (the thread's
+// item — column, quad — stays fixed; its row advances); per-row taps and weights (they differ between the lanes of an iteration
+// now) come from small LDS tables.  Every component goes through the same __fmul_rn / __fadd_rn sequence as the scalar kernel:
+// bit-identical (tested against it, the two-kernel form and the oracle).
+typedef float ms_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ms_f4 ms_mul4(ms_f4 a, float w) { return ms_f4{__fmul_rn(a.x, w), __fmul_rn(a.y, w), __fmul_rn(a.z, w), __fmul_rn(a.w, w)}; }
+__device__ __forceinline__ ms_f4 ms_mad4(ms_f4 acc, ms_f4 a, float w) {
+    return ms_f4{__fadd_rn(acc.x, __fmul_rn(a.x, w)), __fadd_rn(acc.y, __fmul_rn(a.y, w)), __fadd_rn(acc.z, __fmul_rn(a.z, w)), __fadd_rn(acc.w, __fmul_rn(a.w, w))};
+}
+template <int R>
+__global__ void __launch_bounds__(256) multiscale_fused_v4_kernel(MapView src, int C, int MS_TX, int crop_top, int crop_left, const int* __restrict__ xi,
+                                                                  const float* __restrict__ xw, const int* __restrict__ yi, const float* __restrict__ yw,
+                                                                  int dst_h, int dst_w, float divisor, int init, float* __restrict__ accum,
+                                                                  int lo_hz_floats) {
+    constexpr int CG = 19, Q = 5, PP = 20;                             // channels of a group, quads and LDS floats per pixel
+    extern __shared__ __attribute__((aligned(16))) float msv[];
+    __shared__ __attribute__((aligned(16))) float s_cw[8][4];          // the up-sampling's phase weights
+    __shared__ int s_coff[8];
+    __shared__ __attribute__((aligned(16))) int s_yi[MS_TY][4];        // the tile's row taps of the resize
+    __shared__ __attribute__((aligned(16))) float s_yw[MS_TY][4];
+    const CubicTable& ct = g_cubic[R == 4 ? 0 : 1];
+    const int tiles_x = (dst_w + MS_TX - 1) / MS_TX;
+    const int x0 = (blockIdx.x % tiles_x) * MS_TX, y0 = (blockIdx.x / tiles_x) * MS_TY;
+    const int x1 = min(x0 + MS_TX, dst_w), y1 = min(y0 + MS_TY, dst_h);
+    const int c0 = blockIdx.y * CG, n = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int ua = crop_top + yi[y0 * 4], ub = crop_top + yi[(y1 - 1) * 4 + 3];
+    const int va = crop_left + xi[x0 * 4], vb = crop_left + xi[(x1 - 1) * 4 + 3];
+    const int UH = ub - ua + 1, UW = vb - va + 1;
+    const int la = ua / R - 2, ka = va / R - 2;
+    const int LH = ub / R + 2 - la + 1, LW = vb / R + 2 - ka + 1;
+    float* lo = msv;                                                   // [LH][LW][PP]
+    float* hz = lo + LH * LW * PP;                                     // [LH][UW][PP]
+    float* up = msv + lo_hz_floats;                                    // [UH][UW][PP]
+    float* h2 = msv;                                                   // [UH][x1 - x0][PP]  (lo / hz are dead by then)
+    const int TXn = x1 - x0, TYn = y1 - y0;
+    const int W1 = UW * Q, W2 = TXn * Q;                               // items of a row of the x R passes / of the output passes (<= 256: host)
+    const int rp1 = 256 / W1, rp2 = 256 / W2;                          // rows per iteration
+    const int rs1 = tid / W1, it1 = tid - rs1 * W1;                    // this thread's row slot and item in the x R passes
+    const int rs2 = tid / W2, it2 = tid - rs2 * W2;                    // ... in the output passes
+    const bool on1 = rs1 < rp1, on2 = rs2 < rp2;
+    const int u1 = it1 / Q, q1 = it1 - u1 * Q;                         // column of the x R map, quad
+    const int xl2 = it2 / Q, q2 = it2 - xl2 * Q;                       // output column, quad
+    if (tid < 8) { s_coff[tid] = ct.off[tid]; }
+    if (tid < 32) s_cw[tid >> 2][tid & 3] = ct.w[tid >> 2][tid & 3];
+    if (tid >= 64 && tid < 64 + MS_TY * 4) {
+        const int r = (tid - 64) >> 2, t = tid & 3, y = min(y0 + r, dst_h - 1);
+        s_yi[r][t] = crop_top + yi[y * 4 + t] - ua;
+        s_yw[r][t] = yw[y * 4 + t];
+    }
+    // the resize's column taps and the accumulator values of this thread's outputs: requested now, used after the passes
+    int off2[4];
+    float w2t[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        off2[t] = on2 ? xi[(x0 + xl2) * 4 + t] : 0;
+        w2t[t] = on2 ? xw[(x0 + xl2) * 4 + t] : 0.f;
+    }
+    const int nq2 = q2 == Q - 1 ? CG - 4 * (Q - 1) : 4;               // channels of this thread's quad (the last one holds 3)
+    constexpr int MS_RPT = MS_TY / 2;                                  // output rows per thread: the tile's items fill at most half the threads (host)
+    ms_f4 accv[MS_RPT];
+#pragma unroll
+    for (int r = 0; r < MS_RPT; ++r) {
+        const int yr = rs2 + r * rp2;
+        accv[r] = ms_f4{0.f, 0.f, 0.f, 0.f};
+        if (!init && on2 && yr < TYn) {
+            const float* a = accum + (((int64_t)n * dst_h + y0 + yr) * dst_w + x0 + xl2) * C + c0 + 4 * q2;
+            if (nq2 == 4) { const F4U v = *(const F4U*)a; accv[r] = ms_f4{v.v[0], v.v[1], v.v[2], v.v[3]}; }
+            else accv[r] = ms_f4{a[0], a[1], a[2], 0.f};
+        }
+    }
+    const float* base = src.base + (int64_t)n * src.ns + (int64_t)c0 * src.cs;
+    if (tid < LH * LW) {                                               // lanes along x: contiguous runs of the channel planes
+        const int j = tid / LW, k = tid - j * LW;
+        const float* p = base + (int64_t)clampi(la + j, 0, src.h - 1) * src.ys + (int64_t)clampi(ka + k, 0, src.w - 1) * src.xs;
+        float v[PP];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) v[c] = p[(int64_t)c * src.cs];
+        v[CG] = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) *(ms_f4*)(lo + tid * PP + 4 * q) = ms_f4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    }
+    __syncthreads();
+    if (on1) {                                                         // up-sampling, horizontal
+        const int X = va + u1, qx = X / R, px = X - qx * R;
+        const int off = (qx + s_coff[px] - 1 - ka) * PP + 4 * q1;
+        const ms_f4 w = *(const ms_f4*)s_cw[px];
+        for (int j = rs1; j < LH; j += rp1) {
+            const float* row = lo + j * LW * PP + off;
+            ms_f4 a = ms_mul4(*(const ms_f4*)row, w.x);
+            a = ms_mad4(a, *(const ms_f4*)(row + PP), w.y);
+            a = ms_mad4(a, *(const ms_f4*)(row + 2 * PP), w.z);
+            a = ms_mad4(a, *(const ms_f4*)(row + 3 * PP), w.w);
+            *(ms_f4*)(hz + (j * UW + u1) * PP + 4 * q1) = a;
+        }
+    }
+    __syncthreads();
+    if (on1) {                                                         // up-sampling, vertical
+        const int col = u1 * PP + 4 * q1;
+        for (int v = rs1; v < UH; v += rp1) {
+            const int Y = ua + v, qy = Y / R, py = Y - qy * R;
+            const ms_f4 w = *(const ms_f4*)s_cw[py];
+            const float* rows = hz + (qy + s_coff[py] - 1 - la) * UW * PP + col;
+            ms_f4 t = ms_mul4(*(const ms_f4*)rows, w.x);
+            t = ms_mad4(t, *(const ms_f4*)(rows + UW * PP), w.y);
+            t = ms_mad4(t, *(const ms_f4*)(rows + 2 * UW * PP), w.z);
+            t = ms_mad4(t, *(const ms_f4*)(rows + 3 * UW * PP), w.w);
+            *(ms_f4*)(up + v * UW * PP + col) = t;
+        }
+    }
+    __syncthreads();
+    if (on2) {                                                         // resize, horizontal
+#pragma unroll
+        for (int t = 0; t < 4; ++t) off2[t] = (crop_left + off2[t] - va) * PP + 4 * q2;
+        for (int v = rs2; v < UH; v += rp2) {
+            const float* row = up + v * UW * PP;
+            ms_f4 a = ms_mul4(*(const ms_f4*)(row + off2[0]), w2t[0]);
+            a = ms_mad4(a, *(const ms_f4*)(row + off2[1]), w2t[1]);
+            a = ms_mad4(a, *(const ms_f4*)(row + off2[2]), w2t[2]);
+            a = ms_mad4(a, *(const ms_f4*)(row + off2[3]), w2t[3]);
+            *(ms_f4*)(h2 + (v * TXn + xl2) * PP + 4 * q2) = a;
+        }
+    }
+    __syncthreads();
+    if (on2) {                                                         // resize, vertical + accumulate
+        const int col = xl2 * PP + 4 * q2;
+#pragma unroll
+        for (int r = 0; r < MS_RPT; ++r) {
+            const int yr = rs2 + r * rp2;
+            if (yr >= TYn) break;
+            const int4 ri = *(const int4*)s_yi[yr];
+            const ms_f4 w = *(const ms_f4*)s_yw[yr];
+            ms_f4 o = ms_mul4(*(const ms_f4*)(h2 + ri.x * TXn * PP + col), w.x);
+            o = ms_mad4(o, *(const ms_f4*)(h2 + ri.y * TXn * PP + col), w.y);
+            o = ms_mad4(o, *(const ms_f4*)(h2 + ri.z * TXn * PP + col), w.z);
+            o = ms_mad4(o, *(const ms_f4*)(h2 + ri.w * TXn * PP + col), w.w);
+            const ms_f4 res = ms_f4{__fadd_rn(accv[r].x, __fdiv_rn(o.x, divisor)), __fadd_rn(accv[r].y, __fdiv_rn(o.y, divisor)),
+                                    __fadd_rn(accv[r].z, __fdiv_rn(o.z, divisor)), __fadd_rn(accv[r].w, __fdiv_rn(o.w, divisor))};
+            float* dst = accum + (((int64_t)n * dst_h + y0 + yr) * dst_w + x0 + xl2) * C + c0 + 4 * q2;
+            if (nq2 == 4) { F4U v; v.v[0] = res.x; v.v[1] = res.y; v.v[2] = res.z; v.v[3] = res.w; *(F4U*)dst = v; }
+            else { dst[0] = res.x; dst[1] = res.y; dst[2] = res.z; }
+        }
+    }
+}
+
 // host: x R rows / columns the largest tile of a geometry touches, for tiles of MS_TY x tx output pixels
 void multiscale_fused_extent(const int* xi, const int* yi, int dst_h, int dst_w, int tx, int* uh_max, int* uw_max) {
     *uh_max = *uw_max = 0;
@@ -462,6 +609,47 @@ void multiscale_fused_plan(const int* xi, const int* yi, int dst_h, int dst_w, i
         const double cost = wg * ((dst_w + tx - 1) / tx) * (occ >= 4 ? 1.0 : occ == 3 ? 1.05 : occ == 2 ? 1.4 : 2.2);
         if (cost < best) { best = cost; *tx_best = tx; *uh_max = uh; *uw_max = uw; }
     }
+}
+// host, once per geometry: tile width of the four-channel kernel (five items and 20 LDS floats per pixel; a row of a pass must fit
+// the 256 threads; 256 / items rows per iteration)
+void multiscale_fused_plan_v4(const int* xi, const int* yi, int dst_h, int dst_w, int R, int* tx_best, int* uh_max, int* uw_max) {
+    constexpr int Q = 5, PP = 20;
+    double best = 1e300;
+    *tx_best = 0; *uh_max = 0; *uw_max = 0;
+    for (int tx = 8; tx <= 25; ++tx) {                                  // tx * 5 <= 128: two or more output rows per iteration, at most four per thread
+        int uh = 0, uw = 0;
+        multiscale_fused_extent(xi, yi, dst_h, dst_w, tx, &uh, &uw);
+        if (uw * Q > 256) continue;
+        const int lh = (uh - 1) / R + 6, lw = (uw - 1) / R + 6;
+        const size_t lo_hz = (size_t)(lh * lw + lh * uw) * PP, h2 = (size_t)uh * tx * PP;
+        const size_t lds = ((lo_hz > h2 ? lo_hz : h2) + (size_t)uh * uw * PP) * sizeof(float) + 1024;
+        if (lh * lw > 256 || lds > 64 * 1024) continue;
+        const int rp1 = 256 / (uw * Q), rp2 = 256 / (tx * Q);
+        const double wg = (double)((lh + rp1 - 1) / rp1) + (double)((uh + rp1 - 1) / rp1) + (double)((uh + rp2 - 1) / rp2) + (double)((MS_TY + rp2 - 1) / rp2) + 4.0;
+        const int occ = (int)((160 * 1024) / (lds + 512));
+        const double cost = wg * ((dst_w + tx - 1) / tx) * (occ >= 4 ? 1.0 : occ == 3 ? 1.05 : occ == 2 ? 1.4 : 2.2);
+        if (cost < best) { best = cost; *tx_best = tx; *uh_max = uh; *uw_max = uw; }
+    }
+}
+// *used = false: the geometry does not fit; the caller takes the scalar fused kernel (or the two-kernel form)
+hipError_t launch_multiscale_fused_v4(const MapView& src, int N, int C, int ratio, int crop_top, int crop_left, const int* xi, const float* xw,
+                                      const int* yi, const float* yw, int dst_h, int dst_w, float divisor, int init, float* accum,
+                                      int tx, int uh_max, int uw_max, hipStream_t s, bool* used) {
+    *used = false;
+    constexpr int CG = 19, Q = 5, PP = 20;
+    if ((ratio != 4 && ratio != 8) || C % CG != 0 || tx <= 0 || uh_max <= 0 || uw_max <= 0 || uw_max * Q > 256 || tx * Q > 128) return hipSuccess;
+    const int lh_max = (uh_max - 1) / ratio + 6, lw_max = (uw_max - 1) / ratio + 6;
+    const size_t lo_hz = (size_t)(lh_max * lw_max + lh_max * uw_max) * PP, h2 = (size_t)uh_max * tx * PP;
+    const size_t a = lo_hz > h2 ? lo_hz : h2, lds = (a + (size_t)uh_max * uw_max * PP) * sizeof(float);
+    if (lh_max * lw_max > 256 || lds > 96 * 1024) return hipSuccess;
+    static LdsAttrOnce attr4, attr8;
+    hipError_t e = ratio == 4 ? attr4.ensure((const void*)multiscale_fused_v4_kernel<4>, 96 * 1024) : attr8.ensure((const void*)multiscale_fused_v4_kernel<8>, 96 * 1024);
+    if (e != hipSuccess) return e;
+    *used = true;
+    const dim3 grid(((dst_w + tx - 1) / tx) * ((dst_h + MS_TY - 1) / MS_TY), C / CG, N);
+    if (ratio == 4) hipLaunchKernelGGL(multiscale_fused_v4_kernel<4>, grid, dim3(256), lds, s, src, C, tx, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
+    else hipLaunchKernelGGL(multiscale_fused_v4_kernel<8>, grid, dim3(256), lds, s, src, C, tx, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
+    return hipGetLastError();
 }
 template <int R, int CG, int K1, int K2>
 static hipError_t launch_multiscale_fused_t(const MapView& src, int N, int C, int tx, int crop_top, int crop_left, const int* xi, const float* xw,

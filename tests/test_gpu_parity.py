@@ -538,15 +538,18 @@ def test_multiscale_accumulate_bit_exact(eng):
 
 
 def test_multiscale_fused_kernel_equals_the_two_kernel_form_and_the_oracle(monkeypatch):
-    """multiscale_fused_kernel (x8 / x4 up-sample + crop + cubic resize + avg += m / n through LDS, no up-sampled map in memory)
-    against the two-kernel form (LWP_MS_FUSED=0) BIT FOR BIT on 19- and 38-channel maps, batches of two, magnifying and minifying
+    """multiscale_fused_v4_kernel (four channels per lane) and multiscale_fused_kernel (one; LWP_MS_VEC=0) — x8 / x4 up-sample + crop +
+    cubic resize + avg += m / n through LDS, no up-sampled map in memory — against the two-kernel form (LWP_MS_FUSED=0) BIT FOR BIT on 19- and 38-channel maps, batches of two, magnifying and minifying
     resizes (ratios 0.5 / 1 / 1.5 / 2 of the reference's scale list), crops on every side, output sizes that are no multiple of the
     8 x 16 tile, first scale (init) and later scales; one geometry also against the oracle.  17-channel maps take the two-kernel
     form in both engines (no multiple of the channel group)."""
     monkeypatch.setenv("LWP_MS_FUSED", "0")
     e_two = Engine(0)
     monkeypatch.delenv("LWP_MS_FUSED")
-    e_fus = Engine(0)
+    monkeypatch.setenv("LWP_MS_VEC", "0")
+    e_sca = Engine(0)                                   # the scalar fused kernel (one channel per lane)
+    monkeypatch.delenv("LWP_MS_VEC")
+    e_fus = Engine(0)                                   # default: four channels per lane
     rng = np.random.RandomState(5)
     cases = [  # (C, h, w, ratio, pad, dst_h, dst_w)
         (19, 23, 46, 8, [0, 3, 0, 3], 150, 301), (38, 23, 46, 8, [20, 30, 12, 18], 184, 328), (38, 46, 46, 8, [92, 20, 92, 20], 368, 656),
@@ -558,7 +561,9 @@ def test_multiscale_fused_kernel_equals_the_two_kernel_form_and_the_oracle(monke
             acc0 = (rng.rand(2, dh, dw, C_).astype(np.float32) - 0.5)
             a = e_two.multiscale_accumulate(acc0.copy(), maps, ratio, pad, 3, init=init)
             b = e_fus.multiscale_accumulate(acc0.copy(), maps, ratio, pad, 3, init=init)
+            c = e_sca.multiscale_accumulate(acc0.copy(), maps, ratio, pad, 3, init=init)
             assert np.array_equal(a, b), (C_, h, w, ratio, pad, dh, dw, init)
+            assert np.array_equal(a, c), (C_, h, w, ratio, pad, dh, dw, init)
     heat, _, _ = synth.make_pose_maps(3, 23, 46, 21)
     acc0 = (synth.uniform((150, 301, 19), 78) - 0.5).astype(np.float32)
     ref = post_ref.multiscale_accumulate(acc0.copy(), heat, 8, [0, 3, 0, 3], 301, 150, 3)

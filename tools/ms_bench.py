@@ -25,7 +25,7 @@ for name, h, w, pad in geos:
 print("scales 0.5 + 1 + 1.5, both maps: %%.2f ms" %% (tot / 1e3))
 ''' % ROOT
 batch = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].isdigit() else "32"
-cfgs = [("fused", {}), ("two kernels (LWP_MS_FUSED=0)", {"LWP_MS_FUSED": "0"})]
+cfgs = [("fused, four channels per lane", {}), ("fused, one channel per lane (LWP_MS_VEC=0)", {"LWP_MS_VEC": "0"}), ("two kernels (LWP_MS_FUSED=0)", {"LWP_MS_FUSED": "0"})]
 if "--tx" in sys.argv:
     cfgs = [("fused, %s-column tiles" % t, {"LWP_MS_TX": t}) for t in ("11", "13", "16", "26", "32")] + cfgs
 for tag, env in cfgs:
