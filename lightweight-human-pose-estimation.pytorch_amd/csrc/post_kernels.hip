@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256) multiscale_fused_v4_kernel(MapView src, i
     const int tiles_x = (dst_w + MS_TX - 1) / MS_TX;
     const int x0 = (blockIdx.x % tiles_x) * MS_TX, y0 = (blockIdx.x / tiles_x) * MS_TY;
     const int x1 = min(x0 + MS_TX, dst_w), y1 = min(y0 + MS_TY, dst_h);
-    const int c0 = blockIdx.y * CG, n = blockIdx.z;
+    const int n = blockIdx.z;
     const int tid = threadIdx.x;
     const int ua = crop_top + yi[y0 * 4], ub = crop_top + yi[(y1 - 1) * 4 + 3];
     const int va = crop_left + xi[x0 * 4], vb = crop_left + xi[(x1 - 1) * 4 + 3];
@@ -491,6 +491,12 @@ __global__ void __launch_bounds__(256) multiscale_fused_v4_kernel(MapView src, i
         w2t[t] = on2 ? xw[(x0 + xl2) * 4 + t] : 0.f;
     }
     const int nq2 = q2 == Q - 1 ? CG - 4 * (Q - 1) : 4;               // channels of this thread's quad (the last one holds 3)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) off2[t] = (crop_left + off2[t] - va) * PP + 4 * q2;
+    // the workgroup walks ALL channel groups of its tile (two for the 38 PAF channels): one workgroup writes whole accumulator lines
+    // (two workgroups per tile shared every line: 1006 against 2 x 394 us at scale 0.5) and the tables are set up once
+    for (int c0 = 0; c0 < C; c0 += CG) {
+    if (c0) __syncthreads();                                           // the previous group's passes are done with the LDS
     constexpr int MS_RPT = MS_TY / 2;                                  // output rows per thread: the tile's items fill at most half the threads (host)
     ms_f4 accv[MS_RPT];
 #pragma unroll
@@ -544,8 +550,6 @@ __global__ void __launch_bounds__(256) multiscale_fused_v4_kernel(MapView src, i
     }
     __syncthreads();
     if (on2) {                                                         // resize, horizontal
-#pragma unroll
-        for (int t = 0; t < 4; ++t) off2[t] = (crop_left + off2[t] - va) * PP + 4 * q2;
         for (int v = rs2; v < UH; v += rp2) {
             const float* row = up + v * UW * PP;
             ms_f4 a = ms_mul4(*(const ms_f4*)(row + off2[0]), w2t[0]);
@@ -575,6 +579,7 @@ __global__ void __launch_bounds__(256) multiscale_fused_v4_kernel(MapView src, i
             else { dst[0] = res.x; dst[1] = res.y; dst[2] = res.z; }
         }
     }
+    }   // channel groups
 }
 
 // host: x R rows / columns the largest tile of a geometry touches, for tiles of MS_TY x tx output pixels
@@ -646,7 +651,7 @@ hipError_t launch_multiscale_fused_v4(const MapView& src, int N, int C, int rati
     hipError_t e = ratio == 4 ? attr4.ensure((const void*)multiscale_fused_v4_kernel<4>, 96 * 1024) : attr8.ensure((const void*)multiscale_fused_v4_kernel<8>, 96 * 1024);
     if (e != hipSuccess) return e;
     *used = true;
-    const dim3 grid(((dst_w + tx - 1) / tx) * ((dst_h + MS_TY - 1) / MS_TY), C / CG, N);
+    const dim3 grid(((dst_w + tx - 1) / tx) * ((dst_h + MS_TY - 1) / MS_TY), 1, N);       // a workgroup walks all channel groups
     if (ratio == 4) hipLaunchKernelGGL(multiscale_fused_v4_kernel<4>, grid, dim3(256), lds, s, src, C, tx, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
     else hipLaunchKernelGGL(multiscale_fused_v4_kernel<8>, grid, dim3(256), lds, s, src, C, tx, crop_top, crop_left, xi, xw, yi, yw, dst_h, dst_w, divisor, init, accum, (int)a);
     return hipGetLastError();
